@@ -1,0 +1,16 @@
+"""MI355X-native caption generation behind the generate API of MicaKil/image-captioning.
+
+Public surface (mirrors the reference's names for this path):
+  gen_caption                         captioner.py:9-30
+  transformer.ImageCaptioner          models/transformer.py:296-640
+  lstm.BasicImageCaptioner            models/basic.py:53 + models/image_captioner.py
+  lstm.IntermediateImageCaptioner     models/intermediate.py:70 + models/image_captioner.py
+  Vocabulary                          dataset/vocabulary.py (generate-side subset)
+All compute goes through csrc/libmic_hip.so (include/mic_hip.h); importing fails if it is not built.
+"""
+from . import _lib  # noqa: F401  (loads libmic_hip.so or raises)
+from .captioner import gen_caption
+from .vocabulary import Vocabulary, PAD, SOS, EOS, UNK
+from . import transformer, lstm, encoders, weights
+
+__all__ = ["gen_caption", "Vocabulary", "transformer", "lstm", "encoders", "weights", "PAD", "SOS", "EOS", "UNK"]

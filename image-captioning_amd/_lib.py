@@ -1,0 +1,154 @@
+"""ctypes binding of libmic_hip.so (declared in include/mic_hip.h).
+
+The library is the product; there is no fallback.  Importing this module loads the shared object
+built by ``csrc/build.sh`` and raises if it is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+F32, BF16 = 0, 1
+MAX_BEAM, MAX_LAYERS = 8, 8
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmic_hip.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("in_", vp), ("w", vp), ("bias", vp), ("res", vp), ("out", vp),
+                ("dtype", i32), ("out_dtype", i32), ("res_dtype", i32),
+                ("M", i32), ("N", i32), ("K", i32),
+                ("OH", i32), ("OW", i32), ("IH", i32), ("IW", i32),
+                ("in_img_stride", i64), ("in_row_stride", i64),
+                ("in_pix_stride", i32), ("kw_taps", i32), ("run", i32),
+                ("stride", i32), ("pad_h", i32), ("pad_w", i32),
+                ("ldc", i32), ("ld_res", i32), ("relu", i32)]
+
+
+class BeamState(C.Structure):
+    _fields_ = [("score", vp), ("len", vp), ("seq", vp), ("anc", vp)]
+
+
+class ConvLayer(C.Structure):
+    _fields_ = [("w", vp), ("bias", vp), ("cin", i32), ("cout", i32), ("kh", i32), ("kw", i32),
+                ("stride", i32), ("pad", i32), ("relu", i32)]
+
+
+class Resnet50(C.Structure):
+    _fields_ = [("dtype", i32), ("stem", ConvLayer), ("blocks_per_stage", i32 * 4), ("conv", (ConvLayer * 4) * 16)]
+
+
+_TR_W = ["self_in_w", "self_out_w", "cross_q_w", "cross_kv_w", "cross_out_w", "ff1_w", "ff2_w"]
+_TR_B = ["self_in_b", "self_out_b", "cross_q_b", "cross_kv_b", "cross_out_b", "ff1_b", "ff2_b"]
+_TR_LN = ["ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b"]
+
+
+class TrLayer(C.Structure):
+    _fields_ = [(n, vp) for n in _TR_W + _TR_B + _TR_LN]
+
+
+class TrDecoder(C.Structure):
+    _fields_ = [("dtype", i32), ("H", i32), ("heads", i32), ("layers", i32), ("vocab", i32), ("pos_rows", i32),
+                ("tok_emb", vp), ("pos_emb", vp), ("layer", TrLayer * MAX_LAYERS), ("out_w", vp), ("out_b", vp)]
+
+
+class TrWorkspace(C.Structure):
+    _fields_ = [("N", i32), ("t_cap", i32), ("S", i32), ("rows_per_image", i32),
+                ("x", vp), ("xt", vp), ("y", vp), ("qkv", vp), ("o", vp), ("ffh", vp), ("logits", vp),
+                ("kcache", vp * MAX_LAYERS), ("vcache", vp * MAX_LAYERS), ("cross_kv", vp * MAX_LAYERS),
+                ("attn", vp), ("top_val", vp), ("top_idx", vp)]
+
+
+class LstmDecoder(C.Structure):
+    _fields_ = [("dtype", i32), ("E", i32), ("Hd", i32), ("layers", i32), ("vocab", i32), ("kind", i32),
+                ("kpad", i32 * MAX_LAYERS), ("embed", vp), ("w", vp * MAX_LAYERS), ("b", vp * MAX_LAYERS),
+                ("ln_g", vp), ("ln_b", vp), ("out_w", vp), ("out_b", vp), ("out_k", i32)]
+
+
+class LstmWorkspace(C.Structure):
+    _fields_ = [("N", i32), ("xh", vp * MAX_LAYERS), ("h", vp * MAX_LAYERS), ("c", vp * MAX_LAYERS),
+                ("gates", vp), ("hn", vp), ("hnt", vp), ("logits", vp), ("scratch", vp)]
+
+
+P = C.POINTER
+# name -> (restype, argtypes); must list every symbol include/mic_hip.h declares
+SIGNATURES = {
+    "mic_last_error": (C.c_char_p, []),
+    "mic_version": (C.c_int, []),
+    "mic_conv2d": (C.c_int, [P(ConvDesc), vp]),
+    "mic_pack_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_global_avgpool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_embed_pos": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_self_attn_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_cross_attn_step": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, f32, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_lstm_cell": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_gather_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "mic_logsoftmax_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, vp, vp, vp, vp]),
+    "mic_sample_multinomial": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
+    "mic_beam_select": (C.c_int, [P(BeamState), P(BeamState), vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, vp]),
+    "mic_beam_finalize": (C.c_int, [P(BeamState), vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "mic_sample_update": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_resnet50_workspace_bytes": (C.c_int64, [P(Resnet50), C.c_int, C.c_int, C.c_int]),
+    "mic_resnet50_forward": (C.c_int, [P(Resnet50), vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]),
+    "mic_tr_cross_kv": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, vp]),
+    "mic_tr_step": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "mic_tr_beam_steps": (C.c_int, [P(TrDecoder), P(TrWorkspace), P(BeamState), vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, vp]),
+    "mic_tr_sample_steps": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, vp]),
+    "mic_lstm_step": (C.c_int, [P(LstmDecoder), P(LstmWorkspace), vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+}
+
+
+class MicError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with image-captioning_amd/csrc/build.sh "
+            "(there is no CPU or PyTorch fallback for the generate path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    """Turn a non-zero return code into an exception carrying mic_last_error()."""
+    if rc != 0:
+        msg = lib.mic_last_error().decode("utf-8", "replace")
+        kind = "argument error" if rc < 0 else f"hipError {rc}"
+        raise MicError(f"{what or 'libmic_hip'}: {kind}: {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+    if torch_dtype == torch.float32:
+        return F32
+    if torch_dtype == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unsupported compute dtype {torch_dtype}; use torch.float32 or torch.bfloat16")

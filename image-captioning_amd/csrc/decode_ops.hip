@@ -1,0 +1,353 @@
+// Per-step decoder kernels that are not GEMMs: embedding, LayerNorm, single-query attention over
+// the per-beam KV cache / per-image cross K/V, LSTM cell, beam-state row gather.
+// These are HBM/L2-bandwidth and latency bound (one new token per row); every global access is a
+// 16-byte (or 4-float) vector along the hidden axis.
+#include "mic_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_pos_kernel(const int32_t* __restrict__ ids, int ld_ids, int pos, const float* __restrict__ tok_emb,
+                                 const float* __restrict__ pos_emb, float* __restrict__ x, T* __restrict__ xt, int ld_xt,
+                                 int N, int H, int vocab) {
+    const int hv = H >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * hv) return;
+    const int n = i / hv, c = (i - n * hv) << 2;
+    int id = ids[(long long)n * ld_ids + pos];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never index outside the table
+    float4 v = *reinterpret_cast<const float4*>(tok_emb + (long long)id * H + c);
+    if (pos_emb) {
+        const float4 p = *reinterpret_cast<const float4*>(pos_emb + (long long)pos * H + c);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (x) *reinterpret_cast<float4*>(x + (long long)n * H + c) = v;
+    if (xt) {
+        T* o = xt + (long long)n * ld_xt + c;
+        o[0] = from_f32<T>(v.x); o[1] = from_f32<T>(v.y); o[2] = from_f32<T>(v.z); o[3] = from_f32<T>(v.w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one wave per row, 4 rows per block
+template <typename T>
+__global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                 float* __restrict__ y, T* __restrict__ yt, int ld_yt, int N, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* xr = x + (long long)row * H;
+    float s = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + i);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + i);
+        const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += (a * a + bb * bb) + (c * c + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + 1e-5f);
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + i);
+        const float4 gg = *reinterpret_cast<const float4*>(g + i), bb = *reinterpret_cast<const float4*>(b + i);
+        float4 o;
+        o.x = (v.x - mean) * rstd * gg.x + bb.x;
+        o.y = (v.y - mean) * rstd * gg.y + bb.y;
+        o.z = (v.z - mean) * rstd * gg.z + bb.z;
+        o.w = (v.w - mean) * rstd * gg.w + bb.w;
+        if (y) *reinterpret_cast<float4*>(y + (long long)row * H + i) = o;
+        if (yt) {
+            T* t = yt + (long long)row * ld_yt + i;
+            t[0] = from_f32<T>(o.x); t[1] = from_f32<T>(o.y); t[2] = from_f32<T>(o.z); t[3] = from_f32<T>(o.w);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-query attention: one workgroup (256 threads) per row, all heads.
+//   phase A: score[h][p] = q_h . k_p      (16-lane group per (h,p) pair, 16 B per lane per load)
+//   phase B: softmax over p per head      (one wave per head)
+//   phase C: o = sum_p w[h][p] * v_p      (threads = 16-byte channel chunks x position groups)
+struct AttnArgs {
+    const float* q;   // self: qkv [N][3H]; cross: q [N][ldq]
+    int ldq;
+    void* kcache;     // self: [N][t_cap][H]
+    void* vcache;
+    const int32_t* anc;
+    const void* kv;   // cross: [B][S][2H]
+    int t, t_cap, S, rows_per_image;
+    void* o;
+    int ld_o;
+    float* attn_out;
+    int ld_attn;
+    float attn_scale;
+    int accumulate;
+    int N, H, heads;
+};
+
+template <typename T, bool SELF>
+__global__ __launch_bounds__(256) void attn_step_kernel(const AttnArgs a) {
+    constexpr int VEC = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, heads = a.heads, hd = H / heads;
+    const int P = SELF ? a.t + 1 : a.S;
+    const int C = H / VEC;
+    const int npg = 256 / C > 0 ? 256 / C : 1;
+    float* q_s = smem;                 // [H]
+    float* sc = q_s + H;               // [heads][P]
+    float* part = sc + ((heads * P + 3) & ~3);  // [npg][H]
+    int* anc_s = reinterpret_cast<int*>(part + npg * H);  // [P] (self only)
+
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float scale = sqrtf(1.0f / (float)hd);
+    const float* qrow = a.q + (long long)n * a.ldq;
+    for (int i = tid; i < H; i += 256) q_s[i] = qrow[i] * scale;
+    if constexpr (SELF) {
+        T* kc = (T*)a.kcache + ((long long)n * a.t_cap + a.t) * H;
+        T* vc = (T*)a.vcache + ((long long)n * a.t_cap + a.t) * H;
+        for (int i = tid; i < H; i += 256) {
+            kc[i] = from_f32<T>(qrow[H + i]);
+            vc[i] = from_f32<T>(qrow[2 * H + i]);
+        }
+        for (int p = tid; p < a.t; p += 256) anc_s[p] = a.anc ? a.anc[(long long)n * a.t_cap + p] : n;
+    }
+    __syncthreads();
+
+    // rows of keys / values for position p; position t of the self form comes from the fresh
+    // projection (rounded through T, i.e. exactly what was just written to the cache)
+    auto load_kv = [&](int p, int off, bool value, float (&f)[VEC]) {
+        if constexpr (SELF) {
+            if (p == a.t) {
+                const float* src = qrow + (value ? 2 * H : H) + off;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] = to_f32<T>(from_f32<T>(src[e]));
+                return;
+            }
+            const T* base = (const T*)(value ? a.vcache : a.kcache) + ((long long)anc_s[p] * a.t_cap + p) * H + off;
+            const Vec16<T> v = ld16(base);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = to_f32<T>(v.v[e]);
+        } else {
+            const T* base = (const T*)a.kv + ((long long)(n / a.rows_per_image) * a.S + p) * 2 * H + (value ? H : 0) + off;
+            const Vec16<T> v = ld16(base);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = to_f32<T>(v.v[e]);
+        }
+    };
+
+    // phase A
+    {
+        const int grp = tid >> 4, gl = tid & 15;
+        const int npairs = heads * P;
+        const int chunks = hd / VEC;
+        for (int pair = grp; pair < npairs; pair += 16) {
+            const int h = pair / P, p = pair - h * P;
+            float s = 0.f;
+            for (int c = gl; c < chunks; c += 16) {
+                float f[VEC];
+                load_kv(p, h * hd + c * VEC, false, f);
+                const float* qq = q_s + h * hd + c * VEC;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s = fmaf(qq[e], f[e], s);
+            }
+            s += __shfl_xor(s, 8, 16);
+            s += __shfl_xor(s, 4, 16);
+            s += __shfl_xor(s, 2, 16);
+            s += __shfl_xor(s, 1, 16);
+            if (gl == 0) sc[pair] = s;
+        }
+    }
+    __syncthreads();
+    // phase B
+    {
+        const int wv = tid >> 6, lane = tid & 63;
+        for (int h = wv; h < heads; h += 4) {
+            float* row = sc + h * P;
+            float m = -INFINITY;
+            for (int p = lane; p < P; p += 64) m = fmaxf(m, row[p]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int p = lane; p < P; p += 64) {
+                const float e = expf(row[p] - m);
+                row[p] = e;
+                s += e;
+            }
+            s = wave_sum(s);
+            const float inv = 1.0f / s;
+            for (int p = lane; p < P; p += 64) row[p] *= inv;
+        }
+    }
+    __syncthreads();
+    if constexpr (!SELF) {
+        if (a.attn_out) {
+            const float hs = a.attn_scale / (float)heads;
+            for (int p = tid; p < P; p += 256) {
+                float s = 0.f;
+                for (int h = 0; h < heads; ++h) s += sc[h * P + p];
+                float* dst = a.attn_out + (long long)n * a.ld_attn + p;
+                *dst = (a.accumulate ? *dst : 0.f) + s * hs;
+            }
+        }
+    }
+    // phase C
+    {
+        const int pg = tid / C, c = tid - pg * C;
+        if (pg < npg) {
+            const int h = (c * VEC) / hd;
+            float acc[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+            for (int p = pg; p < P; p += npg) {
+                float f[VEC];
+                load_kv(p, c * VEC, true, f);
+                const float wgt = sc[h * P + p];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, f[e], acc[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) part[pg * H + c * VEC + e] = acc[e];
+        }
+    }
+    __syncthreads();
+    T* orow = (T*)a.o + (long long)n * a.ld_o;
+    for (int i = tid; i < H; i += 256) {
+        float s = 0.f;
+        for (int g = 0; g < npg; ++g) s += part[g * H + i];
+        orow[i] = from_f32<T>(s);
+    }
+}
+
+template <typename T, bool SELF> int launch_attn(const AttnArgs& a, hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    const int P = SELF ? a.t + 1 : a.S;
+    const int C = a.H / VEC;
+    const int npg = 256 / C > 0 ? 256 / C : 1;
+    const size_t lds = sizeof(float) * ((size_t)a.H + ((a.heads * P + 3) & ~3) + (size_t)npg * a.H) + sizeof(int) * (SELF ? P : 0);
+    MIC_ARG_CHECK(lds <= 64 * 1024, "attention step: %zu bytes of LDS needed (H=%d heads=%d positions=%d)", lds, a.H, a.heads, P);
+    hipLaunchKernelGGL((attn_step_kernel<T, SELF>), dim3(a.N), dim3(256), lds, s, a);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int check_attn_dims(const char* who, int dtype, int N, int H, int heads) {
+    MIC_ARG_CHECK(dtype == MIC_F32 || dtype == MIC_BF16, "%s: bad dtype %d", who, dtype);
+    MIC_ARG_CHECK(N > 0 && H > 0 && heads > 0 && H % heads == 0, "%s: bad sizes N=%d H=%d heads=%d", who, N, H, heads);
+    const int vec = 16 / (int)mic_dtype_size(dtype);
+    MIC_ARG_CHECK((H / heads) % vec == 0, "%s: head_dim=%d must be a multiple of %d", who, H / heads, vec);
+    MIC_ARG_CHECK(H / vec <= 256, "%s: H=%d too large for one workgroup per row", who, H);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename T>
+__global__ void lstm_cell_kernel(const float* __restrict__ gates, float* __restrict__ c, float* __restrict__ h, T* ht0, int ld0,
+                                 T* ht1, int ld1, int N, int Hd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Hd) return;
+    const int n = i / Hd, j = i - n * Hd;
+    const float* g = gates + (long long)n * 4 * Hd;
+    const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[Hd + j]), gg = tanhf(g[2 * Hd + j]), og = sigmoidf_(g[3 * Hd + j]);
+    const float cn = fg * c[i] + ig * gg;
+    const float hn = og * tanhf(cn);
+    c[i] = cn;
+    h[i] = hn;
+    if (ht0) ht0[(long long)n * ld0 + j] = from_f32<T>(hn);
+    if (ht1) ht1[(long long)n * ld1 + j] = from_f32<T>(hn);
+}
+
+__global__ void gather_rows_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const int32_t* __restrict__ idx,
+                                   int rows, int words) {
+    const long long total = (long long)rows * words;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / words), w = (int)(i - (long long)r * words);
+        dst[i] = src[(long long)idx[r] * words + w];
+    }
+}
+
+}  // namespace
+
+extern "C" int mic_embed_pos(const int32_t* ids, int ld_ids, int pos, const float* tok_emb, const float* pos_emb, float* x,
+                             void* xt, int ld_xt, int dtype, int N, int H, int vocab, void* stream) {
+    MIC_ARG_CHECK(ids && tok_emb && (x || xt), "mic_embed_pos: null pointer");
+    MIC_ARG_CHECK(N > 0 && H > 0 && H % 4 == 0 && vocab > 0 && pos >= 0, "mic_embed_pos: bad sizes N=%d H=%d", N, H);
+    MIC_ARG_CHECK(dtype == MIC_F32 || dtype == MIC_BF16, "mic_embed_pos: bad dtype %d", dtype);
+    const int total = N * (H / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MIC_BF16)
+        hipLaunchKernelGGL(embed_pos_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, ids, ld_ids, pos, tok_emb, pos_emb, x, (bf16_t*)xt, ld_xt, N, H, vocab);
+    else
+        hipLaunchKernelGGL(embed_pos_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, ids, ld_ids, pos, tok_emb, pos_emb, x, (float*)xt, ld_xt, N, H, vocab);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mic_layernorm(const float* x, const float* gamma, const float* beta, float* y, void* yt, int ld_yt, int dtype,
+                             int N, int H, void* stream) {
+    MIC_ARG_CHECK(x && gamma && beta && (y || yt), "mic_layernorm: null pointer");
+    MIC_ARG_CHECK(N > 0 && H > 0 && H % 4 == 0, "mic_layernorm: bad sizes N=%d H=%d", N, H);
+    MIC_ARG_CHECK(dtype == MIC_F32 || dtype == MIC_BF16, "mic_layernorm: bad dtype %d", dtype);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MIC_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, y, (bf16_t*)yt, ld_yt, N, H);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, y, (float*)yt, ld_yt, N, H);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mic_self_attn_step(const float* qkv, void* kcache, void* vcache, const int32_t* anc, int t, int t_cap, void* o,
+                                  int ld_o, int dtype, int N, int H, int heads, void* stream) {
+    MIC_ARG_CHECK(qkv && kcache && vcache && o, "mic_self_attn_step: null pointer");
+    MIC_TRY(check_attn_dims("mic_self_attn_step", dtype, N, H, heads));
+    MIC_ARG_CHECK(t >= 0 && t < t_cap && ld_o >= H, "mic_self_attn_step: t=%d t_cap=%d ld_o=%d", t, t_cap, ld_o);
+    AttnArgs a{};
+    a.q = qkv; a.ldq = 3 * H; a.kcache = kcache; a.vcache = vcache; a.anc = anc; a.t = t; a.t_cap = t_cap;
+    a.o = o; a.ld_o = ld_o; a.N = N; a.H = H; a.heads = heads;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == MIC_BF16 ? launch_attn<bf16_t, true>(a, s) : launch_attn<float, true>(a, s);
+}
+
+extern "C" int mic_cross_attn_step(const float* q, int ldq, const void* kv, int S, int rows_per_image, void* o, int ld_o,
+                                   float* attn_out, int ld_attn, float attn_scale, int accumulate, int dtype, int N, int H,
+                                   int heads, void* stream) {
+    MIC_ARG_CHECK(q && kv && o, "mic_cross_attn_step: null pointer");
+    MIC_TRY(check_attn_dims("mic_cross_attn_step", dtype, N, H, heads));
+    MIC_ARG_CHECK(S > 0 && rows_per_image > 0 && ldq >= H && ld_o >= H, "mic_cross_attn_step: bad sizes S=%d", S);
+    MIC_ARG_CHECK(!attn_out || ld_attn >= S, "mic_cross_attn_step: ld_attn=%d < S=%d", ld_attn, S);
+    AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.kv = kv; a.S = S; a.rows_per_image = rows_per_image; a.o = o; a.ld_o = ld_o;
+    a.attn_out = attn_out; a.ld_attn = ld_attn; a.attn_scale = attn_scale; a.accumulate = accumulate;
+    a.N = N; a.H = H; a.heads = heads;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == MIC_BF16 ? launch_attn<bf16_t, false>(a, s) : launch_attn<float, false>(a, s);
+}
+
+extern "C" int mic_lstm_cell(const float* gates, float* c, float* h, void* ht0, int ld0, void* ht1, int ld1, int dtype, int N,
+                             int Hd, void* stream) {
+    MIC_ARG_CHECK(gates && c && h && N > 0 && Hd > 0, "mic_lstm_cell: bad arguments");
+    MIC_ARG_CHECK(dtype == MIC_F32 || dtype == MIC_BF16, "mic_lstm_cell: bad dtype %d", dtype);
+    const int total = N * Hd;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MIC_BF16)
+        hipLaunchKernelGGL(lstm_cell_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, gates, c, h, (bf16_t*)ht0, ld0, (bf16_t*)ht1, ld1, N, Hd);
+    else
+        hipLaunchKernelGGL(lstm_cell_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, gates, c, h, (float*)ht0, ld0, (float*)ht1, ld1, N, Hd);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mic_gather_rows(const void* src, void* dst, const int32_t* idx, int rows, int row_bytes, void* stream) {
+    MIC_ARG_CHECK(src && dst && idx && rows > 0 && row_bytes > 0 && row_bytes % 4 == 0, "mic_gather_rows: bad arguments");
+    MIC_ARG_CHECK(src != dst, "mic_gather_rows: in-place gather is not supported");
+    const long long total = (long long)rows * (row_bytes / 4);
+    long long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, (uint32_t*)dst, idx, rows, row_bytes / 4);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}

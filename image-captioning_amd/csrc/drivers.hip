@@ -1,0 +1,264 @@
+// Native drivers: chain the kernels of one phase (encoder trunk, one decoder step, a run of search
+// steps) on one stream so the host makes one call per phase instead of one per kernel.
+#include "mic_common.h"
+
+namespace {
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// dense linear layer y[M][ldc] = act(x[M][ld_in] * W^T + b + res)
+int linear(int dtype, const void* x, int ld_in, int M, int K, const void* w, const float* bias, const void* res, int res_dtype,
+           int ld_res, void* out, int out_dtype, int ldc, int N, int relu, hipStream_t s) {
+    mic_conv_desc d{};
+    d.in = x; d.w = w; d.bias = bias; d.res = res; d.out = out;
+    d.dtype = dtype; d.out_dtype = out_dtype; d.res_dtype = res_dtype;
+    d.M = M; d.N = N; d.K = K;
+    d.OH = d.OW = d.IH = d.IW = 1;
+    d.in_img_stride = ld_in; d.in_row_stride = 0; d.in_pix_stride = 4;
+    d.kw_taps = 1; d.run = K; d.stride = 1; d.pad_h = d.pad_w = 0;
+    d.ldc = ldc; d.ld_res = ld_res; d.relu = relu;
+    return mic_conv2d(&d, s);
+}
+
+// fused conv layer on a dense NHWC tensor [B][IH][IW][cin]
+int conv_layer(int dtype, const mic_conv_layer& L, const void* in, int B, int IH, int IW, const void* res, void* out, int* OHo,
+               int* OWo, hipStream_t s) {
+    const int OH = (IH + 2 * L.pad - L.kh) / L.stride + 1, OW = (IW + 2 * L.pad - L.kw) / L.stride + 1;
+    mic_conv_desc d{};
+    d.in = in; d.w = L.w; d.bias = L.bias; d.res = res; d.out = out;
+    d.dtype = d.out_dtype = d.res_dtype = dtype;
+    d.M = B * OH * OW; d.N = L.cout; d.K = L.kh * L.kw * L.cin;
+    d.OH = OH; d.OW = OW; d.IH = IH; d.IW = IW;
+    d.in_img_stride = (int64_t)IH * IW * L.cin; d.in_row_stride = (int64_t)IW * L.cin; d.in_pix_stride = L.cin;
+    d.kw_taps = L.kw; d.run = L.cin; d.stride = L.stride; d.pad_h = d.pad_w = L.pad;
+    d.ldc = L.cout; d.ld_res = L.cout; d.relu = L.relu;
+    *OHo = OH; *OWo = OW;
+    return mic_conv2d(&d, s);
+}
+
+struct ResnetPlan {
+    int64_t pack, big, mid, total;
+    int Hp, Wp, H1, W1, H2, W2;
+};
+
+ResnetPlan plan_resnet(const mic_resnet50* net, int B, int H, int W) {
+    ResnetPlan p;
+    const int64_t sz = (int64_t)mic_dtype_size(net->dtype);
+    p.Hp = H + 6; p.Wp = W + 8 + (W & 1);  // even row length keeps 16-byte chunk alignment
+    p.H1 = (H + 6 - 7) / 2 + 1; p.W1 = (W + 6 - 7) / 2 + 1;      // stem output
+    p.H2 = (p.H1 + 2 - 3) / 2 + 1; p.W2 = (p.W1 + 2 - 3) / 2 + 1;  // after max-pool
+    p.pack = align_up((int64_t)B * p.Hp * p.Wp * 4 * sz, 256);
+    const int64_t stem = (int64_t)B * p.H1 * p.W1 * 64;
+    const int64_t l1 = (int64_t)B * p.H2 * p.W2 * 256;
+    p.big = align_up((stem > l1 ? stem : l1) * sz, 256);
+    p.mid = align_up((int64_t)B * p.H2 * p.W2 * 128 * sz, 256);
+    p.total = p.pack + 3 * p.big + 2 * p.mid;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int64_t mic_resnet50_workspace_bytes(const mic_resnet50* net, int B, int H, int W) {
+    if (!net || B <= 0 || H < 32 || W < 32) return -1;
+    return plan_resnet(net, B, H, W).total;
+}
+
+extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images, int B, int H, int W, void* workspace,
+                                    int64_t workspace_bytes, void* out, void* stream) {
+    MIC_ARG_CHECK(net && images && workspace && out, "mic_resnet50_forward: null pointer");
+    MIC_ARG_CHECK(B > 0 && H >= 32 && W >= 32, "mic_resnet50_forward: bad image size %dx%d (B=%d)", H, W, B);
+    MIC_ARG_CHECK(net->dtype == MIC_F32 || net->dtype == MIC_BF16, "mic_resnet50_forward: bad dtype");
+    MIC_ARG_CHECK(((uintptr_t)workspace & 255) == 0, "mic_resnet50_forward: workspace must be 256-byte aligned");
+    const ResnetPlan p = plan_resnet(net, B, H, W);
+    MIC_ARG_CHECK(workspace_bytes >= p.total, "mic_resnet50_forward: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)p.total);
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = net->dtype;
+    char* base = (char*)workspace;
+    void* pack = base;
+    void* X[2] = {base + p.pack, base + p.pack + p.big};
+    void* DS = base + p.pack + 2 * p.big;
+    void* T1 = base + p.pack + 3 * p.big;
+    void* T2 = base + p.pack + 3 * p.big + p.mid;
+
+    // stem: image -> zero-bordered 4-channel pixels; each of the 7 kernel rows is one run of
+    // 8 pixels x 4 channels = 32 contiguous elements (the 8th pixel and 4th channel meet zero weights)
+    MIC_TRY(mic_pack_image(images, pack, dt, B, H, W, 3, 3, 3, 5 + (W & 1), s));
+    {
+        const mic_conv_layer& L = net->stem;
+        MIC_ARG_CHECK(L.w && L.cout == 64, "mic_resnet50_forward: stem layer not set");
+        mic_conv_desc d{};
+        d.in = pack; d.w = L.w; d.bias = L.bias; d.out = X[1];
+        d.dtype = d.out_dtype = d.res_dtype = dt;
+        d.M = B * p.H1 * p.W1; d.N = 64; d.K = 7 * 32;
+        d.OH = p.H1; d.OW = p.W1; d.IH = p.Hp; d.IW = p.Wp;
+        d.in_img_stride = (int64_t)p.Hp * p.Wp * 4; d.in_row_stride = (int64_t)p.Wp * 4; d.in_pix_stride = 4;
+        d.kw_taps = 1; d.run = 32; d.stride = 2; d.pad_h = d.pad_w = 0;
+        d.ldc = 64; d.relu = 1;
+        MIC_TRY(mic_conv2d(&d, s));
+    }
+    MIC_TRY(mic_maxpool3x3s2(X[1], X[0], dt, B, p.H1, p.W1, 64, s));
+    int cur = 0, h = p.H2, w = p.W2, bi = 0;
+    int nblocks = 0;
+    for (int st = 0; st < 4; ++st) nblocks += net->blocks_per_stage[st];
+    MIC_ARG_CHECK(nblocks > 0 && nblocks <= 16, "mic_resnet50_forward: %d bottlenecks (max 16)", nblocks);
+    for (int st = 0; st < 4; ++st) {
+        for (int k = 0; k < net->blocks_per_stage[st]; ++k, ++bi) {
+            const mic_conv_layer* L = net->conv[bi];
+            int h1, w1, h2, w2, h3, w3;
+            MIC_TRY(conv_layer(dt, L[0], X[cur], B, h, w, nullptr, T1, &h1, &w1, s));
+            MIC_TRY(conv_layer(dt, L[1], T1, B, h1, w1, nullptr, T2, &h2, &w2, s));
+            const void* idt = X[cur];
+            if (L[3].cout > 0) {
+                int hd, wd;
+                MIC_TRY(conv_layer(dt, L[3], X[cur], B, h, w, nullptr, DS, &hd, &wd, s));
+                idt = DS;
+            }
+            void* dst = (bi == nblocks - 1) ? out : X[cur ^ 1];
+            MIC_TRY(conv_layer(dt, L[2], T2, B, h2, w2, idt, dst, &h3, &w3, s));
+            cur ^= 1; h = h3; w = w3;
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transformer decoder
+// ---------------------------------------------------------------------------------------------
+namespace {
+int check_tr(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
+    MIC_ARG_CHECK(dec && ws, "transformer driver: null pointer");
+    MIC_ARG_CHECK(dec->dtype == MIC_F32 || dec->dtype == MIC_BF16, "transformer driver: bad dtype");
+    MIC_ARG_CHECK(dec->layers >= 1 && dec->layers <= MIC_MAX_LAYERS, "transformer driver: %d layers (max %d)", dec->layers, MIC_MAX_LAYERS);
+    const int epr = 64 / (int)mic_dtype_size(dec->dtype);
+    MIC_ARG_CHECK(dec->H > 0 && dec->H % epr == 0, "transformer driver: hidden size %d must be a multiple of %d", dec->H, epr);
+    MIC_ARG_CHECK(dec->heads > 0 && dec->H % dec->heads == 0, "transformer driver: heads=%d", dec->heads);
+    MIC_ARG_CHECK(ws->N > 0 && ws->t_cap > 0 && ws->S > 0 && ws->rows_per_image > 0 && ws->N % ws->rows_per_image == 0,
+                  "transformer driver: bad workspace geometry");
+    MIC_ARG_CHECK(ws->x && ws->xt && ws->y && ws->qkv && ws->o && ws->ffh && ws->logits, "transformer driver: workspace buffers missing");
+    return 0;
+}
+}  // namespace
+
+extern "C" int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const void* feats, void* stream) {
+    MIC_TRY(check_tr(dec, ws));
+    MIC_ARG_CHECK(feats, "mic_tr_cross_kv: null features");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = dec->H, rows = ws->N / ws->rows_per_image * ws->S;
+    for (int l = 0; l < dec->layers; ++l) {
+        const mic_tr_layer& L = dec->layer[l];
+        MIC_ARG_CHECK(L.cross_kv_w && ws->cross_kv[l], "mic_tr_cross_kv: layer %d pointers missing", l);
+        MIC_TRY(linear(dec->dtype, feats, H, rows, H, L.cross_kv_w, L.cross_kv_b, nullptr, 0, 0, ws->cross_kv[l], dec->dtype, 2 * H,
+                       2 * H, 0, s));
+    }
+    return 0;
+}
+
+extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
+                           const int32_t* anc, int t, int attn_mode, void* stream) {
+    MIC_TRY(check_tr(dec, ws));
+    MIC_ARG_CHECK(tokens && t >= 0 && t < ws->t_cap && t < dec->pos_rows, "mic_tr_step: position %d outside t_cap=%d / table=%d", t,
+                  ws->t_cap, dec->pos_rows);
+    MIC_ARG_CHECK(attn_mode == 0 || ws->attn, "mic_tr_step: attention requested without a buffer");
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
+    MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
+    for (int l = 0; l < L; ++l) {
+        const mic_tr_layer& Y = dec->layer[l];
+        // masked self-attention over the cache + residual + LayerNorm
+        MIC_TRY(linear(dt, ws->xt, H, N, H, Y.self_in_w, Y.self_in_b, nullptr, 0, 0, ws->qkv, MIC_F32, 3 * H, 3 * H, 0, s));
+        MIC_TRY(mic_self_attn_step(ws->qkv, ws->kcache[l], ws->vcache[l], anc, t, ws->t_cap, ws->o, H, dt, N, H, dec->heads, s));
+        MIC_TRY(linear(dt, ws->o, H, N, H, Y.self_out_w, Y.self_out_b, ws->x, MIC_F32, H, ws->y, MIC_F32, H, H, 0, s));
+        MIC_TRY(mic_layernorm(ws->y, Y.ln1_g, Y.ln1_b, ws->x, ws->xt, H, dt, N, H, s));
+        // cross-attention against the image's cached K/V + residual + LayerNorm
+        MIC_TRY(linear(dt, ws->xt, H, N, H, Y.cross_q_w, Y.cross_q_b, nullptr, 0, 0, ws->qkv, MIC_F32, H, H, 0, s));
+        float* ap = nullptr;
+        int ld_attn = 0, accumulate = 0;
+        float scale = 1.f;
+        if (attn_mode == 1) {
+            ap = ws->attn + (int64_t)t * S; ld_attn = ws->t_cap * S; scale = 1.f / (float)L; accumulate = l > 0;
+        } else if (attn_mode == 2) {
+            ap = ws->attn + ((int64_t)l * ws->t_cap + t) * N * S; ld_attn = S;
+        }
+        MIC_TRY(mic_cross_attn_step(ws->qkv, H, ws->cross_kv[l], S, ws->rows_per_image, ws->o, H, ap, ld_attn, scale, accumulate, dt,
+                                    N, H, dec->heads, s));
+        MIC_TRY(linear(dt, ws->o, H, N, H, Y.cross_out_w, Y.cross_out_b, ws->x, MIC_F32, H, ws->y, MIC_F32, H, H, 0, s));
+        MIC_TRY(mic_layernorm(ws->y, Y.ln2_g, Y.ln2_b, ws->x, ws->xt, H, dt, N, H, s));
+        // feed-forward + residual + LayerNorm
+        MIC_TRY(linear(dt, ws->xt, H, N, H, Y.ff1_w, Y.ff1_b, nullptr, 0, 0, ws->ffh, dt, 2 * H, 2 * H, 1, s));
+        MIC_TRY(linear(dt, ws->ffh, 2 * H, N, 2 * H, Y.ff2_w, Y.ff2_b, ws->x, MIC_F32, H, ws->y, MIC_F32, H, H, 0, s));
+        MIC_TRY(mic_layernorm(ws->y, Y.ln3_g, Y.ln3_b, ws->x, ws->xt, H, dt, N, H, s));
+    }
+    return linear(dt, ws->xt, H, N, H, dec->out_w, dec->out_b, nullptr, 0, 0, ws->logits, MIC_F32, dec->vocab, dec->vocab, 0, s);
+}
+
+extern "C" int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const mic_beam_state st[2], int32_t* parent,
+                                 int32_t* live_images, const double* sqrt_tab, int B, int K, int t0, int t1, int eos_id,
+                                 int want_attn, void* stream) {
+    MIC_TRY(check_tr(dec, ws));
+    MIC_ARG_CHECK(st && parent && live_images && sqrt_tab && ws->top_val && ws->top_idx, "mic_tr_beam_steps: null pointer");
+    MIC_ARG_CHECK(B * K == ws->N && ws->rows_per_image == K, "mic_tr_beam_steps: workspace rows %d != B*K = %d*%d", ws->N, B, K);
+    MIC_ARG_CHECK(t0 >= 0 && t1 >= t0 && t1 + 1 <= ws->t_cap, "mic_tr_beam_steps: steps [%d,%d) do not fit t_cap=%d", t0, t1, ws->t_cap);
+    for (int t = t0; t < t1; ++t) {
+        const mic_beam_state* cur = &st[t & 1];
+        const mic_beam_state* nxt = &st[(t + 1) & 1];
+        MIC_TRY(mic_tr_step(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, stream));
+        MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, ws->N, dec->vocab, K, 1.0f, 0, ws->top_val, ws->top_idx, nullptr, stream));
+        MIC_TRY(mic_beam_select(cur, nxt, ws->top_val, ws->top_idx, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t,
+                                ws->t_cap, eos_id, 0, stream));
+    }
+    return 0;
+}
+
+extern "C" int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, int32_t* tokens, uint8_t* finished,
+                                   float* total, int32_t* live_rows, float inv_temp, const float* u, int t0, int t1, int pad_id,
+                                   int eos_id, int want_attn, void* stream) {
+    MIC_TRY(check_tr(dec, ws));
+    MIC_ARG_CHECK(tokens && finished && total && live_rows && ws->top_val && ws->top_idx, "mic_tr_sample_steps: null pointer");
+    MIC_ARG_CHECK(ws->rows_per_image == 1, "mic_tr_sample_steps: one row per image expected");
+    MIC_ARG_CHECK(t0 >= 0 && t1 >= t0 && t1 + 1 <= ws->t_cap, "mic_tr_sample_steps: steps [%d,%d) do not fit t_cap=%d", t0, t1, ws->t_cap);
+    for (int t = t0; t < t1; ++t) {
+        MIC_TRY(mic_tr_step(dec, ws, tokens, ws->t_cap, nullptr, t, want_attn ? 2 : 0, stream));
+        if (u)
+            MIC_TRY(mic_sample_multinomial(ws->logits, dec->vocab, ws->N, dec->vocab, inv_temp, u + (int64_t)t * ws->N, ws->top_val,
+                                           ws->top_idx, stream));
+        else
+            MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, ws->N, dec->vocab, 1, 1.0f, 0, ws->top_val, ws->top_idx, nullptr, stream));
+        MIC_TRY(mic_sample_update(ws->top_val, ws->top_idx, tokens, ws->t_cap, t + 1, finished, total, live_rows + t, ws->N, pad_id,
+                                  eos_id, stream));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM decoders
+// ---------------------------------------------------------------------------------------------
+extern "C" int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, const int32_t* tokens, int ld_tok, int pos,
+                             const void* feat_t, int ld_feat, void* stream) {
+    MIC_ARG_CHECK(dec && ws && (tokens || feat_t), "mic_lstm_step: null pointer");
+    MIC_ARG_CHECK(dec->dtype == MIC_F32 || dec->dtype == MIC_BF16, "mic_lstm_step: bad dtype");
+    MIC_ARG_CHECK(dec->layers >= 1 && dec->layers <= MIC_MAX_LAYERS && dec->E > 0 && dec->Hd > 0 && ws->N > 0, "mic_lstm_step: bad sizes");
+    MIC_ARG_CHECK(dec->E % 4 == 0 && dec->Hd % 4 == 0, "mic_lstm_step: E=%d and Hd=%d must be multiples of 4", dec->E, dec->Hd);
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = dec->dtype, N = ws->N, E = dec->E, Hd = dec->Hd, L = dec->layers;
+    const size_t sz = mic_dtype_size(dt);
+    if (feat_t) {
+        MIC_HIP_CHECK(hipMemcpy2DAsync(ws->xh[0], (size_t)dec->kpad[0] * sz, feat_t, (size_t)ld_feat * sz, (size_t)E * sz, N,
+                                       hipMemcpyDeviceToDevice, s));
+    } else {
+        MIC_TRY(mic_embed_pos(tokens, ld_tok, pos, dec->embed, nullptr, nullptr, ws->xh[0], dec->kpad[0], dt, N, E, dec->vocab, s));
+    }
+    for (int l = 0; l < L; ++l) {
+        const int in_dim = l == 0 ? E : Hd;
+        MIC_TRY(linear(dt, ws->xh[l], dec->kpad[l], N, dec->kpad[l], dec->w[l], dec->b[l], nullptr, 0, 0, ws->gates, MIC_F32, 4 * Hd,
+                       4 * Hd, 0, s));
+        void* up = nullptr;
+        int ld_up = 0;
+        if (l + 1 < L) { up = ws->xh[l + 1]; ld_up = dec->kpad[l + 1]; }
+        else if (dec->kind == 0) { up = ws->hnt; ld_up = dec->out_k; }
+        MIC_TRY(mic_lstm_cell(ws->gates, ws->c[l], ws->h[l], (char*)ws->xh[l] + (size_t)in_dim * sz, dec->kpad[l], up, ld_up, dt, N, Hd, s));
+    }
+    if (dec->kind == 1)
+        MIC_TRY(mic_layernorm(ws->h[L - 1], dec->ln_g, dec->ln_b, ws->hn, ws->hnt, dec->out_k, dt, N, Hd, s));
+    return linear(dt, ws->hnt, dec->out_k, N, dec->out_k, dec->out_w, dec->out_b, nullptr, 0, 0, ws->logits, MIC_F32, dec->vocab,
+                  dec->vocab, 0, s);
+}

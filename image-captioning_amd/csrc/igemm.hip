@@ -1,0 +1,291 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
+//
+//   out[m, n] = act( sum_k X[m, k] * W[n, k] + bias[n] + res[m, n] )
+//
+// X is gathered on the fly from a pixel-major (NHWC) activation tensor: row m is output pixel
+// (b, oh, ow) and k walks (tap, channel) with `run` contiguous elements per tap, so both operands
+// are K-contiguous and feed the MFMA fragments with 16-byte LDS reads.  One k-tile is 64 bytes of
+// K per row (32 bf16 or 16 fp32).  The weight fragment is the MFMA A operand and the activation
+// fragment the B operand, so every lane ends up with 4 consecutive output channels of one pixel
+// and the epilogue stores (and reads bias/residual) 8-16 bytes per lane.
+//
+// Pipeline per workgroup (256 threads = 2x2 waves): global -> registers for tile k+1 is issued
+// before the MFMAs of tile k and written to the other LDS buffer after them; one barrier per tile.
+#include "mic_common.h"
+
+namespace {
+
+struct IgemmArgs {
+    const void* in;
+    const void* w;
+    const float* bias;
+    const void* res;
+    void* out;
+    int M, N, K;
+    int OHW, OW, IH, IW;
+    long long img_stride, row_stride;
+    int pix_stride, kw_taps, run, stride, pad_h, pad_w;
+    int ldc, ld_res, relu, out_dtype, res_dtype;
+    int tiles_m, tiles_n, nk, vec_ok;
+};
+
+// LDS tile image: rows of 64 bytes (4 chunks of 16 B).  Chunk q of row r is stored at chunk
+// q ^ (2 * bit3(r)): with that, the four 16-lane groups a ds_read_b128 is served in each touch 16
+// distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int lds_off(int row, int q) { return row * 64 + ((q ^ (((row >> 3) & 1) << 1)) << 4); }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const uint4& wf, const uint4& xf, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, xf),
+                                                      acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // 16x16x4 f32 MFMA: lane l supplies k = l>>4.  Each lane holds 4 consecutive k of its chunk, so
+    // MFMA e covers k = {4q+e}: the four together sum the whole 16-element k-tile.
+    __device__ static __forceinline__ void run(const uint4& wf, const uint4& xf, f32x4_t& acc) {
+        const f32x4_t a = __builtin_bit_cast(f32x4_t, wf), b = __builtin_bit_cast(f32x4_t, xf);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+    constexpr int EPR = 4 * VEC;              // K elements per tile row (64 bytes)
+    constexpr int XC = BM * 4 / 256, WC = BN * 4 / 256;
+    constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 MFMA tiles per wave along m / n
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * 64];
+    unsigned char* const sX = smem;
+    unsigned char* const sW = smem + 2 * BM * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // Blocks b and b+8 share an XCD (and its L2): give each XCD a contiguous range of tiles so that
+    // the n-tiles reading the same activation rows hit one L2.
+    int lid;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int m0 = (lid / a.tiles_n) * BM, n0 = (lid % a.tiles_n) * BN;
+
+    const T* __restrict__ in = (const T*)a.in;
+    const T* __restrict__ w = (const T*)a.w;
+
+    // per-thread gather coordinates of its activation chunks (fixed over the k loop)
+    long long x_img[XC];
+    int x_h[XC], x_w[XC], x_dst[XC];
+    bool x_ok[XC];
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+        const int c = tid + i * 256, row = c >> 2, q = c & 3;
+        int m = m0 + row;
+        x_ok[i] = m < a.M;
+        m = x_ok[i] ? m : a.M - 1;
+        const int b = m / a.OHW, r = m - b * a.OHW, oh = r / a.OW, ow = r - oh * a.OW;
+        x_img[i] = (long long)b * a.img_stride + q * VEC;
+        x_h[i] = oh * a.stride - a.pad_h;
+        x_w[i] = ow * a.stride - a.pad_w;
+        x_dst[i] = lds_off(row, q);
+    }
+    const T* w_src[WC];
+    int w_dst[WC];
+#pragma unroll
+    for (int i = 0; i < WC; ++i) {
+        const int c = tid + i * 256, row = c >> 2, q = c & 3;
+        w_src[i] = w + (long long)(n0 + row) * a.K + q * VEC;
+        w_dst[i] = lds_off(row, q);
+    }
+
+    uint4 xr[XC], wr[WC];
+    int kh = 0, kw = 0, c0 = 0;  // tap position of the tile being loaded (block-uniform)
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+            const int ih = x_h[i] + kh, iw = x_w[i] + kw;
+            const bool ok = x_ok[i] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+            const T* p = in + x_img[i] + (long long)ih * a.row_stride + (long long)iw * a.pix_stride + c0;
+            xr[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WC; ++i) {
+            wr[i] = *reinterpret_cast<const uint4*>(w_src[i]);
+            w_src[i] += EPR;
+        }
+        c0 += EPR;
+        if (c0 == a.run) {
+            c0 = 0;
+            if (++kw == a.kw_taps) { kw = 0; ++kh; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XC; ++i) *reinterpret_cast<uint4*>(sX + buf * BM * 64 + x_dst[i]) = xr[i];
+#pragma unroll
+        for (int i = 0; i < WC; ++i) *reinterpret_cast<uint4*>(sW + buf * BN * 64 + w_dst[i]) = wr[i];
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    int xf_off[TM], wf_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xf_off[i] = lds_off(wm * (BM / 2) + i * 16 + (lane & 15), lane >> 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wf_off[j] = lds_off(wn * (BN / 2) + j * 16 + (lane & 15), lane >> 4);
+
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < a.nk; ++kt) {
+        const bool more = kt + 1 < a.nk;
+        if (more) load_tile();
+        uint4 xf[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const uint4*>(sX + cur * BM * 64 + xf_off[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(sW + cur * BN * 64 + wf_off[j]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: lane holds channels n..n+3 of pixel m for each (j, i) tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+        if (n >= a.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < a.N) bv[e] = a.bias[n + e];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+            if (m >= a.M) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bv[e];
+            const bool full = a.vec_ok && n + 3 < a.N;
+            if (a.res) {
+                const long long ro = (long long)m * a.ld_res + n;
+                if (a.res_dtype == MIC_F32) {
+                    const float* r = (const float*)a.res + ro;
+                    if (full) {
+                        const float4 t = *reinterpret_cast<const float4*>(r);
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < a.N) v[e] += r[e];
+                    }
+                } else {
+                    const bf16_t* r = (const bf16_t*)a.res + ro;
+                    if (full) {
+                        struct alignas(8) B4 { bf16_t v[4]; };
+                        const B4 t = *reinterpret_cast<const B4*>(r);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)t.v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < a.N) v[e] += (float)r[e];
+                    }
+                }
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const long long oo = (long long)m * a.ldc + n;
+            if (a.out_dtype == MIC_F32) {
+                float* o = (float*)a.out + oo;
+                if (full) {
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) o[e] = v[e];
+                }
+            } else {
+                bf16_t* o = (bf16_t*)a.out + oo;
+                if (full) {
+                    struct alignas(8) B4 { bf16_t v[4]; } p;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p.v[e] = (bf16_t)v[e];
+                    *reinterpret_cast<B4*>(o) = p;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) o[e] = (bf16_t)v[e];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN> int launch(IgemmArgs& a, hipStream_t s) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    const int grid = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), 0, s, a);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T> int dispatch(IgemmArgs& a, hipStream_t s) {
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (t128 >= 192) return launch<T, 128, 128>(a, s);
+    return launch<T, 64, 64>(a, s);
+}
+
+}  // namespace
+
+extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
+    MIC_ARG_CHECK(d && d->in && d->w && d->out, "mic_conv2d: null pointer");
+    MIC_ARG_CHECK(d->dtype == MIC_F32 || d->dtype == MIC_BF16, "mic_conv2d: bad dtype %d", d->dtype);
+    MIC_ARG_CHECK(d->out_dtype == MIC_F32 || d->out_dtype == MIC_BF16, "mic_conv2d: bad out_dtype %d", d->out_dtype);
+    MIC_ARG_CHECK(!d->res || d->res_dtype == MIC_F32 || d->res_dtype == MIC_BF16, "mic_conv2d: bad res_dtype");
+    MIC_ARG_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "mic_conv2d: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    const int epr = 64 / (int)mic_dtype_size(d->dtype);
+    MIC_ARG_CHECK(d->run > 0 && d->run % epr == 0, "mic_conv2d: run=%d must be a multiple of %d", d->run, epr);
+    MIC_ARG_CHECK(d->kw_taps > 0 && d->K % d->run == 0 && (d->K / d->run) % d->kw_taps == 0,
+                  "mic_conv2d: K=%d is not taps*run (run=%d, kw_taps=%d)", d->K, d->run, d->kw_taps);
+    MIC_ARG_CHECK(d->OH > 0 && d->OW > 0 && d->M % (d->OH * d->OW) == 0, "mic_conv2d: M=%d not a multiple of OH*OW", d->M);
+    MIC_ARG_CHECK(d->stride > 0 && d->IH > 0 && d->IW > 0 && d->ldc >= d->N, "mic_conv2d: bad geometry");
+    const int vec = 16 / (int)mic_dtype_size(d->dtype);
+    MIC_ARG_CHECK(d->in_pix_stride % 4 == 0 && d->in_row_stride % vec == 0 && d->in_img_stride % vec == 0 &&
+                      ((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0,
+                  "mic_conv2d: input strides / pointers must keep 16-byte alignment");
+    // pixel stride may be smaller than a chunk only when chunks still start 16-byte aligned
+    MIC_ARG_CHECK((d->in_pix_stride * (int)mic_dtype_size(d->dtype)) % 8 == 0, "mic_conv2d: pixel stride alignment");
+    IgemmArgs a;
+    a.in = d->in; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.OHW = d->OH * d->OW; a.OW = d->OW; a.IH = d->IH; a.IW = d->IW;
+    a.img_stride = d->in_img_stride; a.row_stride = d->in_row_stride;
+    a.pix_stride = d->in_pix_stride; a.kw_taps = d->kw_taps; a.run = d->run;
+    a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+    a.ldc = d->ldc; a.ld_res = d->ld_res; a.relu = d->relu;
+    a.out_dtype = d->out_dtype; a.res_dtype = d->res_dtype;
+    a.nk = d->K / epr;
+    const size_t osz = mic_dtype_size(d->out_dtype);
+    a.vec_ok = (d->ldc % 4 == 0) && (((uintptr_t)d->out) % (4 * osz) == 0) &&
+               (!d->res || (d->ld_res % 4 == 0 && ((uintptr_t)d->res) % 16 == 0));
+    hipStream_t s = (hipStream_t)stream;
+    return d->dtype == MIC_BF16 ? dispatch<bf16_t>(a, s) : dispatch<float>(a, s);
+}

@@ -1,0 +1,83 @@
+// Internal helpers shared by the kernels of libmic_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mic_hip.h"
+
+#define MIC_WAVE 64
+
+// ---- error plumbing: every entry point returns 0, a negative argument error, or a hipError_t ----
+void mic_set_error(const char* fmt, ...);
+
+#define MIC_ARG_CHECK(cond, ...)                      \
+    do {                                              \
+        if (!(cond)) {                                \
+            mic_set_error(__VA_ARGS__);               \
+            return MIC_ERR_ARG;                       \
+        }                                             \
+    } while (0)
+
+#define MIC_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            mic_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                              \
+        }                                                                                \
+    } while (0)
+
+#define MIC_LAUNCH_CHECK() MIC_HIP_CHECK(hipGetLastError())
+
+#define MIC_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+// ---- element types ----
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+static inline size_t mic_dtype_size(int dt) { return dt == MIC_BF16 ? 2 : 4; }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector of T: 4 floats or 8 bf16
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    float v[4];
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16_t v[8];
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+    uint4 r = *reinterpret_cast<const uint4*>(p);
+    return __builtin_bit_cast(Vec16<T>, r);
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& v) {
+    *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,374 @@
+// Search kernels: log-softmax + top-K over the vocabulary, inverse-CDF sampling, beam selection /
+// reorder, best-beam extraction, greedy bookkeeping.  Pure bandwidth / latency work: one pass of
+// wavefront reductions per row of logits, and integer + fp64 bookkeeping per image.
+#include "mic_common.h"
+
+namespace {
+
+constexpr int KMAX = MIC_MAX_BEAM;
+
+struct KV {
+    float key;
+    int idx;
+};
+// a ranks before b: larger key first, lower index on ties
+__device__ __forceinline__ bool before(const KV& a, const KV& b) { return a.key > b.key || (a.key == b.key && a.idx < b.idx); }
+
+__device__ __forceinline__ KV wave_best(KV v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        KV t;
+        t.key = __shfl_xor(v.key, o, 64);
+        t.idx = __shfl_xor(v.idx, o, 64);
+        if (before(t, v)) v = t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one 256-thread workgroup per row of logits
+template <int K>
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, int ld, int V, float inv_temp,
+                                                              int rank_raw, float* __restrict__ out_val,
+                                                              int32_t* __restrict__ out_idx, float* __restrict__ lse) {
+    __shared__ float red[4];
+    __shared__ KV wbest[4];
+    __shared__ int winner;
+    const int tid = threadIdx.x;
+    const float* x = logits + (long long)blockIdx.x * ld;
+
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i] * inv_temp);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) s += expf(x[i] * inv_temp - m);
+    s = block_sum(s, red);
+    const float logs = logf(s);
+    if (lse && tid == 0) lse[blockIdx.x] = m + logs;
+
+    // thread-local sorted top-K of its strided elements (ascending index order => strict '>' keeps
+    // the lower index ahead on ties)
+    KV loc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) loc[k] = KV{-INFINITY, 0x7fffffff};
+    for (int i = tid; i < V; i += 256) {
+        const float xs = x[i] * inv_temp;
+        KV c{rank_raw ? x[i] : (xs - m) - logs, i};
+        if (before(c, loc[K - 1])) {
+            loc[K - 1] = c;
+#pragma unroll
+            for (int k = K - 1; k > 0; --k) {
+                if (before(loc[k], loc[k - 1])) {
+                    const KV t = loc[k - 1];
+                    loc[k - 1] = loc[k];
+                    loc[k] = t;
+                }
+            }
+        }
+    }
+    // K rounds of block-wide selection over the heads of the per-thread lists
+    for (int r = 0; r < K; ++r) {
+        const KV b = wave_best(loc[0]);
+        if ((tid & 63) == 0) wbest[tid >> 6] = b;
+        __syncthreads();
+        KV best = wbest[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (before(wbest[w], best)) best = wbest[w];
+        if (loc[0].idx == best.idx && best.idx != 0x7fffffff) {
+            // this thread owned the winner: emit and pop
+            if (tid >= 0) {
+                const float xs = x[best.idx] * inv_temp;
+                out_val[(long long)blockIdx.x * K + r] = (xs - m) - logs;
+                out_idx[(long long)blockIdx.x * K + r] = best.idx;
+            }
+#pragma unroll
+            for (int k = 0; k < K - 1; ++k) loc[k] = loc[k + 1];
+            loc[K - 1] = KV{-INFINITY, 0x7fffffff};
+        } else if (best.idx == 0x7fffffff && tid == 0) {
+            out_val[(long long)blockIdx.x * K + r] = -INFINITY;  // fewer than K entries in the row
+            out_idx[(long long)blockIdx.x * K + r] = 0;
+        }
+        __syncthreads();
+    }
+    (void)winner;
+}
+
+// one 256-thread workgroup per row; thread i owns the contiguous slice [i*chunk, (i+1)*chunk)
+__global__ __launch_bounds__(256) void sample_multinomial_kernel(const float* __restrict__ logits, int ld, int V, float inv_temp,
+                                                                 const float* __restrict__ u, float* __restrict__ out_val,
+                                                                 int32_t* __restrict__ out_idx) {
+    __shared__ float red[4];
+    __shared__ double scan[256];
+    __shared__ int first;
+    const int tid = threadIdx.x;
+    const float* x = logits + (long long)blockIdx.x * ld;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i] * inv_temp);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) s += expf(x[i] * inv_temp - m);
+    s = block_sum(s, red);
+    const float logs = logf(s);
+    const int chunk = (V + 255) / 256;
+    const int lo = tid * chunk, hi = min(V, lo + chunk);
+    double part = 0.0;
+    for (int i = lo; i < hi; ++i) part += (double)expf((x[i] * inv_temp - m) - logs);
+    scan[tid] = part;
+    if (tid == 0) first = V - 1;
+    __syncthreads();
+    if (tid == 0) {  // 256-entry exclusive scan, serial: negligible next to the row reads
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            const double t = scan[i];
+            scan[i] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    const double uu = (double)u[blockIdx.x];
+    double run = scan[tid];
+    for (int i = lo; i < hi; ++i) {
+        run += (double)expf((x[i] * inv_temp - m) - logs);
+        if (run > uu) {
+            atomicMin(&first, i);
+            break;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int i = first;
+        out_idx[blockIdx.x] = i;
+        out_val[blockIdx.x] = (x[i] * inv_temp - m) - logs;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// beam selection: one wave per image
+struct BeamArgs {
+    mic_beam_state cur, nxt;
+    const float* top_val;
+    const int32_t* top_idx;
+    int32_t* parent;
+    int32_t* live_images;
+    const double* sqrt_tab;
+    int B, K, n_live_slots, t, t_cap, eos_id, in_place;
+};
+
+__global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
+    constexpr int CMAX = KMAX * KMAX + KMAX;
+    __shared__ double c_key[CMAX], c_score[CMAX];
+    __shared__ int c_slot[CMAX], c_tok[CMAX];
+    __shared__ int s_fin[KMAX], s_off[KMAX], win[KMAX];
+    const int b = blockIdx.x, lane = threadIdx.x, K = a.K;
+    const int base = b * K;
+    const int ns = a.n_live_slots;
+    if (lane < ns) {
+        const int len = a.cur.len[base + lane];
+        s_fin[lane] = a.cur.seq[(long long)(base + lane) * a.t_cap + len - 1] == a.eos_id;
+    }
+    __syncthreads();
+    int n_live = 0, n_fin = 0;
+    for (int i = 0; i < ns; ++i) (s_fin[i] ? n_fin : n_live)++;
+    if (lane == 0) {
+        // position of each slot's first candidate in the reference's candidate list
+        int off = 0, lv = 0, fn = 0;
+        for (int i = 0; i < ns; ++i) {
+            if (a.in_place) {
+                s_off[i] = off;
+                off += s_fin[i] ? 1 : K;
+            } else {
+                s_off[i] = s_fin[i] ? n_live * K + fn : lv * K;
+                (s_fin[i] ? fn : lv)++;
+            }
+        }
+    }
+    __syncthreads();
+    const int ncand = n_live * K + n_fin;
+    // fill candidates: slot i contributes K entries (live) or itself (finished)
+    for (int w = lane; w < ns * K; w += 64) {
+        const int i = w / K, j = w - i * K;
+        const int g = base + i;
+        if (s_fin[i]) {
+            if (j == 0) {
+                const int c = s_off[i];
+                const double sc = a.cur.score[g];
+                c_score[c] = sc;
+                c_key[c] = sc / a.sqrt_tab[a.cur.len[g]];
+                c_slot[c] = i;
+                c_tok[c] = -1;
+            }
+        } else {
+            const int c = s_off[i] + j;
+            const double sc = a.cur.score[g] + (double)a.top_val[(long long)g * K + j];
+            c_score[c] = sc;
+            c_key[c] = sc / a.sqrt_tab[a.cur.len[g] + 1];
+            c_slot[c] = i;
+            c_tok[c] = a.top_idx[(long long)g * K + j];
+        }
+    }
+    __syncthreads();
+    // stable descending rank = number of candidates that sort strictly ahead
+    for (int c = lane; c < ncand; c += 64) {
+        const double k = c_key[c];
+        int rank = 0;
+        for (int o = 0; o < ncand; ++o) {
+            const double ko = c_key[o];
+            rank += (ko > k) || (ko == k && o < c);
+        }
+        if (rank < K) win[rank] = c;
+    }
+    __syncthreads();
+    int any_live = 0;
+    for (int r = 0; r < K; ++r) {
+        const int c = win[r], i = c_slot[c], tok = c_tok[c];
+        const int gs = base + i, gd = base + r;
+        const int len = a.cur.len[gs];
+        const int32_t* sseq = a.cur.seq + (long long)gs * a.t_cap;
+        int32_t* dseq = a.nxt.seq + (long long)gd * a.t_cap;
+        for (int p = lane; p < len; p += 64) dseq[p] = sseq[p];
+        if (a.cur.anc) {
+            const int32_t* sa = a.cur.anc + (long long)gs * a.t_cap;
+            int32_t* da = a.nxt.anc + (long long)gd * a.t_cap;
+            const int na = tok >= 0 ? a.t : len - 1;  // positions this lineage has been run for
+            for (int p = lane; p < na; p += 64) da[p] = sa[p];
+            if (tok >= 0 && lane == 0) da[a.t] = gs;
+        }
+        if (lane == 0) {
+            a.nxt.score[gd] = c_score[c];
+            a.nxt.len[gd] = tok >= 0 ? len + 1 : len;
+            if (tok >= 0) dseq[len] = tok;
+            a.parent[gd] = gs;
+        }
+        any_live |= (tok >= 0 && tok != a.eos_id);
+    }
+    if (lane == 0 && any_live && a.live_images) atomicAdd(a.live_images, 1);
+}
+
+__global__ __launch_bounds__(64) void beam_finalize_kernel(const mic_beam_state st, const double* __restrict__ sqrt_tab, int B, int K,
+                                                           int t_cap, int32_t* __restrict__ tokens, int32_t* __restrict__ lengths,
+                                                           float* __restrict__ score, const float* __restrict__ hist, int S,
+                                                           float* __restrict__ attn_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int best = 0;
+    double bk = st.score[b * K] / sqrt_tab[st.len[b * K]];
+    for (int r = 1; r < K; ++r) {
+        const double k = st.score[b * K + r] / sqrt_tab[st.len[b * K + r]];
+        if (k > bk) { bk = k; best = r; }
+    }
+    const int g = b * K + best, len = st.len[g];
+    for (int p = lane; p < t_cap; p += 64) tokens[(long long)b * t_cap + p] = p < len ? st.seq[(long long)g * t_cap + p] : -1;
+    if (lane == 0) {
+        lengths[b] = len;
+        score[b] = (float)st.score[g];
+    }
+    if (hist && attn_out && st.anc) {
+        for (int s = lane; s < S; s += 64) {
+            float run = 0.f;
+            for (int p = 0; p < len - 1; ++p) {
+                const int src = st.anc[(long long)g * t_cap + p];
+                run += hist[((long long)src * t_cap + p) * S + s];
+                attn_out[((long long)b * t_cap + p) * S + s] = run / (float)(p + 1);
+            }
+        }
+    }
+}
+
+__global__ void sample_update_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx, int32_t* __restrict__ tokens,
+                                     int t_cap, int pos, uint8_t* __restrict__ finished, float* __restrict__ total,
+                                     int32_t* live_rows, int N, int pad_id, int eos_id) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const bool fin = finished[n] != 0;
+    if (total && !fin) total[n] += val[n];
+    const int tok = fin ? pad_id : idx[n];
+    tokens[(long long)n * t_cap + pos] = tok;
+    const bool nf = fin || tok == eos_id;
+    finished[n] = nf;
+    if (!nf && live_rows) atomicAdd(live_rows, 1);
+}
+
+}  // namespace
+
+extern "C" int mic_logsoftmax_topk(const float* logits, int ld, int N, int V, int K, float inv_temp, int rank_raw, float* out_val,
+                                   int32_t* out_idx, float* lse, void* stream) {
+    MIC_ARG_CHECK(logits && out_val && out_idx, "mic_logsoftmax_topk: null pointer");
+    MIC_ARG_CHECK(N > 0 && V > 0 && ld >= V, "mic_logsoftmax_topk: bad sizes N=%d V=%d ld=%d", N, V, ld);
+    MIC_ARG_CHECK(K >= 1 && K <= KMAX, "mic_logsoftmax_topk: K=%d outside [1,%d]", K, KMAX);
+    hipStream_t s = (hipStream_t)stream;
+#define MIC_TOPK_CASE(KK)                                                                                                  \
+    case KK:                                                                                                               \
+        hipLaunchKernelGGL(logsoftmax_topk_kernel<KK>, dim3(N), dim3(256), 0, s, logits, ld, V, inv_temp, rank_raw, out_val, \
+                           out_idx, lse);                                                                                  \
+        break;
+    switch (K) {
+        MIC_TOPK_CASE(1) MIC_TOPK_CASE(2) MIC_TOPK_CASE(3) MIC_TOPK_CASE(4)
+        MIC_TOPK_CASE(5) MIC_TOPK_CASE(6) MIC_TOPK_CASE(7) MIC_TOPK_CASE(8)
+    }
+#undef MIC_TOPK_CASE
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mic_sample_multinomial(const float* logits, int ld, int N, int V, float inv_temp, const float* u, float* out_val,
+                                      int32_t* out_idx, void* stream) {
+    MIC_ARG_CHECK(logits && u && out_val && out_idx, "mic_sample_multinomial: null pointer");
+    MIC_ARG_CHECK(N > 0 && V > 0 && ld >= V, "mic_sample_multinomial: bad sizes N=%d V=%d ld=%d", N, V, ld);
+    hipLaunchKernelGGL(sample_multinomial_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, ld, V, inv_temp, u, out_val, out_idx);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mic_beam_select(const mic_beam_state* cur, const mic_beam_state* nxt, const float* top_val, const int32_t* top_idx,
+                               int32_t* parent, int32_t* live_images, const double* sqrt_tab, int B, int K, int n_live_slots, int t,
+                               int t_cap, int eos_id, int finished_in_place, void* stream) {
+    MIC_ARG_CHECK(cur && nxt && top_val && top_idx && parent && sqrt_tab, "mic_beam_select: null pointer");
+    MIC_ARG_CHECK(cur->score && cur->len && cur->seq && nxt->score && nxt->len && nxt->seq, "mic_beam_select: null state");
+    MIC_ARG_CHECK((cur->anc == nullptr) == (nxt->anc == nullptr), "mic_beam_select: anc must be set in both states or neither");
+    MIC_ARG_CHECK(B > 0 && K >= 1 && K <= KMAX, "mic_beam_select: B=%d K=%d (K <= %d)", B, K, KMAX);
+    MIC_ARG_CHECK(n_live_slots >= 1 && n_live_slots <= K, "mic_beam_select: n_live_slots=%d", n_live_slots);
+    MIC_ARG_CHECK(t >= 0 && t + 2 <= t_cap, "mic_beam_select: step %d does not fit t_cap=%d", t, t_cap);
+    BeamArgs a;
+    a.cur = *cur; a.nxt = *nxt; a.top_val = top_val; a.top_idx = top_idx; a.parent = parent; a.live_images = live_images;
+    a.sqrt_tab = sqrt_tab; a.B = B; a.K = K; a.n_live_slots = n_live_slots; a.t = t; a.t_cap = t_cap; a.eos_id = eos_id;
+    a.in_place = finished_in_place;
+    hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mic_beam_finalize(const mic_beam_state* st, const double* sqrt_tab, int B, int K, int t_cap, int32_t* tokens,
+                                 int32_t* lengths, float* score, const float* attn_hist, int S, float* attn_out, void* stream) {
+    MIC_ARG_CHECK(st && st->score && st->len && st->seq && sqrt_tab && tokens && lengths && score, "mic_beam_finalize: null pointer");
+    MIC_ARG_CHECK(B > 0 && K >= 1 && K <= KMAX && t_cap > 0, "mic_beam_finalize: bad sizes");
+    MIC_ARG_CHECK(!attn_out || (attn_hist && st->anc && S > 0), "mic_beam_finalize: attention output needs hist, anc and S");
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *st, sqrt_tab, B, K, t_cap, tokens, lengths, score,
+                       attn_hist, S, attn_out);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mic_sample_update(const float* val, const int32_t* idx, int32_t* tokens, int t_cap, int pos, uint8_t* finished,
+                                 float* total, int32_t* live_rows, int N, int pad_id, int eos_id, void* stream) {
+    MIC_ARG_CHECK(idx && tokens && finished && N > 0, "mic_sample_update: bad arguments");
+    MIC_ARG_CHECK(!total || val, "mic_sample_update: total needs val");
+    MIC_ARG_CHECK(pos >= 0 && pos < t_cap, "mic_sample_update: pos=%d outside t_cap=%d", pos, t_cap);
+    hipLaunchKernelGGL(sample_update_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, val, idx, tokens, t_cap, pos,
+                       finished, total, live_rows, N, pad_id, eos_id);
+    MIC_LAUNCH_CHECK();
+    return 0;
+}

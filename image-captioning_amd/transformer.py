@@ -1,0 +1,240 @@
+"""Transformer captioner on libmic_hip: host-side mirror of models/transformer.py:296-640.
+
+`ImageCaptioner.generate` keeps the reference's signature and return convention
+(models/transformer.py:394-431): ``(captions, log_probs)`` or ``(captions, log_probs, attn)``.
+The algorithm underneath is the cached formulation of the same search: one new position per step
+for all images and beams at once, keys/values kept per beam slot with an ancestry table instead of
+re-running the prefix, beam bookkeeping on the device in fp64.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import weights as W
+from .encoders import ResNet50Encoder
+from .vocabulary import EOS, PAD, SOS
+
+
+class ImageCaptioner:
+    def __init__(self, vocab, num_heads: int = 2, dtype: torch.dtype = torch.bfloat16, encoder: str = "resnet50",
+                 sync_every: int = 8):
+        if encoder not in ("resnet50", "none"):
+            raise ValueError(f"Encoder {encoder} not recognized")
+        self.vocab = vocab
+        self.num_heads = num_heads
+        self.dtype = dtype
+        self.encoder_kind = encoder
+        self.sync_every = max(1, int(sync_every))
+        self._sd = None
+        self.device = None
+        self.encoder = None
+        self.dec = None
+        self._ws_cache = {}
+
+    # ---- weights ------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts ``checkpoint["model_state"]`` of the reference (plotter/captions.py:396)."""
+        need = ["seq_embedding.token_embedding.weight", "seq_embedding.pos_embedding.weight", "output_layer.linear.weight",
+                "output_layer.linear.bias", "decoder_layers.0.self_attention.mha.in_proj_weight"]
+        missing = [k for k in need if k not in state_dict]
+        if missing:
+            raise KeyError(f"state dict is missing transformer decoder parameters: {missing}")
+        if self.encoder_kind == "resnet50" and "encoder.resnet.0.weight" not in state_dict:
+            raise KeyError("state dict has no ResNet-50 encoder (encoder.resnet.*); construct with encoder='none' "
+                           "to decode from precomputed features")
+        self._sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        self.max_len = self._sd["seq_embedding.pos_embedding.weight"].shape[0]
+        self.device = None
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("image_captioning_amd runs on a HIP device only; there is no CPU path")
+        if self._sd is None:
+            raise RuntimeError("load_state_dict() must be called before to(device)")
+        if self.device == device:
+            return self
+        with torch.cuda.device(device):
+            self.dec, self._dec_keep = W.build_tr_decoder(self._sd, self.num_heads, self.dtype, device)
+            self.encoder = ResNet50Encoder(self._sd, "transformer", self.dtype, device) if self.encoder_kind == "resnet50" else None
+        self.device = device
+        self._ws_cache = {}
+        return self
+
+    def eval(self):
+        return self
+
+    # ---- workspace ----------------------------------------------------------------------------
+    def _workspace(self, N: int, t_cap: int, S: int, rpi: int, K: int, attn_mode: int):
+        key = (N, t_cap, S, rpi, K, attn_mode)
+        hit = self._ws_cache.get(key)
+        if hit is not None:
+            return hit
+        d, dev, H, V, Ly = self.dtype, self.device, self.dec.H, self.dec.vocab, self.dec.layers
+        f32 = torch.float32
+        t = {
+            "x": torch.empty(N, H, dtype=f32, device=dev), "xt": torch.empty(N, H, dtype=d, device=dev),
+            "y": torch.empty(N, H, dtype=f32, device=dev), "qkv": torch.empty(N, 3 * H, dtype=f32, device=dev),
+            "o": torch.empty(N, H, dtype=d, device=dev), "ffh": torch.empty(N, 2 * H, dtype=d, device=dev),
+            "logits": torch.empty(N, V, dtype=f32, device=dev),
+            "kc": torch.zeros(Ly, N, t_cap, H, dtype=d, device=dev), "vc": torch.zeros(Ly, N, t_cap, H, dtype=d, device=dev),
+            "ckv": torch.empty(Ly, N // rpi, S, 2 * H, dtype=d, device=dev),
+            "top_val": torch.empty(N, K, dtype=f32, device=dev), "top_idx": torch.empty(N, K, dtype=torch.int32, device=dev),
+        }
+        if attn_mode == 1:
+            t["attn"] = torch.zeros(N, t_cap, S, dtype=f32, device=dev)
+        elif attn_mode == 2:
+            t["attn"] = torch.zeros(Ly, t_cap, N, S, dtype=f32, device=dev)
+        ws = L.TrWorkspace()
+        ws.N, ws.t_cap, ws.S, ws.rows_per_image = N, t_cap, S, rpi
+        for name in ("x", "xt", "y", "qkv", "o", "ffh", "logits", "top_val", "top_idx"):
+            setattr(ws, name, t[name].data_ptr())
+        for l in range(Ly):
+            ws.kcache[l], ws.vcache[l], ws.cross_kv[l] = t["kc"][l].data_ptr(), t["vc"][l].data_ptr(), t["ckv"][l].data_ptr()
+        ws.attn = t["attn"].data_ptr() if attn_mode else None
+        if len(self._ws_cache) > 4:
+            self._ws_cache.clear()
+        self._ws_cache[key] = (ws, t)
+        return ws, t
+
+    # ---- search -------------------------------------------------------------------------------
+    def _check_feats(self, feats: torch.Tensor) -> torch.Tensor:
+        if feats.dim() != 3 or feats.shape[2] != self.dec.H:
+            raise ValueError(f"expected image tokens of shape (B,S,{self.dec.H}), got {tuple(feats.shape)}")
+        return feats.to(self.device, self.dtype).contiguous()
+
+    def beam_search_ids(self, feats: torch.Tensor, max_len: int, beam_size: int, return_attn: bool = False):
+        """Device beam search (models/transformer.py:576-640).  Returns int32 tokens (B, max_len+1) padded
+        with -1, int32 lengths (B,), fp32 summed log-probs (B,), and fp32 attention (B, max_len+1, S) or None."""
+        if not 1 < beam_size <= L.MAX_BEAM:
+            raise ValueError(f"beam_size must be in [2, {L.MAX_BEAM}], got {beam_size}")
+        feats = self._check_feats(feats)
+        B, S, _ = feats.shape
+        K, dev = beam_size, self.device
+        N, t_cap = B * K, max_len + 1
+        ws, t = self._workspace(N, t_cap, S, K, K, 1 if return_attn else 0)
+        st_t, st = [], (L.BeamState * 2)()
+        for i in range(2):
+            score = torch.zeros(N, dtype=torch.float64, device=dev)
+            ln = torch.ones(N, dtype=torch.int32, device=dev)
+            seq = torch.full((N, t_cap), self.vocab.str_to_idx(SOS), dtype=torch.int32, device=dev)
+            anc = torch.zeros(N, t_cap, dtype=torch.int32, device=dev)
+            st_t.append((score, ln, seq, anc))
+            st[i].score, st[i].len, st[i].seq, st[i].anc = score.data_ptr(), ln.data_ptr(), seq.data_ptr(), anc.data_ptr()
+        parent = torch.empty(N, dtype=torch.int32, device=dev)
+        live = torch.zeros(max(t_cap, 1), dtype=torch.int32, device=dev)
+        # len ** 0.5 exactly as the reference's Python evaluates it (models/transformer.py:627)
+        sqrt_tab = torch.tensor([float(i) ** 0.5 for i in range(t_cap + 2)], dtype=torch.float64).to(dev)
+        stream = L.stream_ptr()
+        L.check(L.lib.mic_tr_cross_kv(C.byref(self.dec), C.byref(ws), feats.data_ptr(), stream), "mic_tr_cross_kv")
+        eos = self.vocab.str_to_idx(EOS)
+        t0 = 0
+        while t0 < max_len:
+            t1 = min(max_len, t0 + self.sync_every)
+            L.check(L.lib.mic_tr_beam_steps(C.byref(self.dec), C.byref(ws), st, parent.data_ptr(), live.data_ptr(),
+                                            sqrt_tab.data_ptr(), B, K, t0, t1, eos, int(return_attn), stream), "mic_tr_beam_steps")
+            t0 = t1
+            if t0 < max_len and int(live[t0 - 1].item()) == 0:  # every image's beams have ended
+                break
+        tokens = torch.empty(B, t_cap, dtype=torch.int32, device=dev)
+        lengths = torch.empty(B, dtype=torch.int32, device=dev)
+        score = torch.empty(B, dtype=torch.float32, device=dev)
+        attn = torch.zeros(B, t_cap, S, dtype=torch.float32, device=dev) if return_attn else None
+        L.check(L.lib.mic_beam_finalize(C.byref(st[t0 & 1]), sqrt_tab.data_ptr(), B, K, t_cap, tokens.data_ptr(), lengths.data_ptr(),
+                                        score.data_ptr(), t["attn"].data_ptr() if return_attn else None, S,
+                                        L.ptr(attn), stream), "mic_beam_finalize")
+        self._keep_alive = (st_t, parent, live, sqrt_tab)
+        return tokens, lengths, score, attn
+
+    def sample_ids(self, feats: torch.Tensor, max_len: int, temp: Optional[float], return_attn: bool = False,
+                   uniforms: Optional[torch.Tensor] = None):
+        """Batched greedy / temperature sampling (models/transformer.py:475-556).  Returns int32 tokens
+        (B, n_tokens), fp32 log-probs (B,), attention (L, steps, B, S) or None."""
+        feats = self._check_feats(feats)
+        B, S, _ = feats.shape
+        dev = self.device
+        hot = temp is not None and temp > 0
+        t_cap = max(max_len, 1)
+        ws, t = self._workspace(B, t_cap, S, 1, 1, 2 if return_attn else 0)
+        tokens = torch.full((B, t_cap), self.vocab.str_to_idx(PAD), dtype=torch.int32, device=dev)
+        tokens[:, 0] = self.vocab.str_to_idx(SOS)
+        finished = torch.zeros(B, dtype=torch.uint8, device=dev)
+        total = torch.zeros(B, dtype=torch.float32, device=dev)
+        live = torch.zeros(t_cap, dtype=torch.int32, device=dev)
+        steps = max_len - 1
+        u = None
+        if hot:
+            u = uniforms if uniforms is not None else torch.rand(max(steps, 1), B, device=dev)
+            u = u.to(dev, torch.float32).contiguous()
+            if u.shape[0] < steps or u.shape[1] != B:
+                raise ValueError(f"uniforms must have shape (>={steps}, {B})")
+        stream = L.stream_ptr()
+        L.check(L.lib.mic_tr_cross_kv(C.byref(self.dec), C.byref(ws), feats.data_ptr(), stream), "mic_tr_cross_kv")
+        t0, done_steps = 0, steps
+        while t0 < steps:
+            t1 = min(steps, t0 + self.sync_every)
+            L.check(L.lib.mic_tr_sample_steps(C.byref(self.dec), C.byref(ws), tokens.data_ptr(), finished.data_ptr(), total.data_ptr(),
+                                              live.data_ptr(), (1.0 / temp) if hot else 1.0, L.ptr(u), t0, t1,
+                                              self.vocab.str_to_idx(PAD), self.vocab.str_to_idx(EOS), int(return_attn), stream),
+                    "mic_tr_sample_steps")
+            lv = live[t0:t1].tolist()
+            t0 = t1
+            if 0 in lv:  # the reference stops right after the step in which the last row finished
+                done_steps = t1 - len(lv) + lv.index(0) + 1
+                break
+        attn = t["attn"][:, :done_steps].clone() if return_attn else None
+        return tokens[:, : done_steps + 1], total, attn
+
+    # ---- reference-compatible API -------------------------------------------------------------
+    def generate(self, images: torch.Tensor, vocab, max_len: int, device, temp: Optional[float], beam_size: int,
+                 no_grad: bool = True, return_attn: bool = False, **kwargs) -> tuple:
+        """models/transformer.py:394-431.  ``no_grad=False`` (used only by the reference's RL training
+        loop, train.py:235) would need autograd through the kernels and is rejected."""
+        if "return_atnn" in kwargs:  # the spelling captioner.py:30 uses
+            return_attn = kwargs.pop("return_atnn")
+        if kwargs:
+            raise TypeError(f"generate() got unexpected keyword arguments {sorted(kwargs)}")
+        if not no_grad:
+            raise NotImplementedError("generate(no_grad=False) is training-only and not supported by the HIP path")
+        self.to(device)
+        eff = min(max_len, self.max_len)
+        feats = self.encode(images)
+        return self.generate_from_features(feats, vocab, eff, temp, beam_size, return_attn)
+
+    def encode(self, images: torch.Tensor) -> torch.Tensor:
+        if self.encoder is None:
+            raise RuntimeError("this captioner was built without an encoder; pass features to generate_from_features")
+        return self.encoder(images)
+
+    def generate_from_features(self, feats, vocab, max_len: int, temp, beam_size: int, return_attn: bool = False,
+                               uniforms=None) -> tuple:
+        """Everything downstream of the encoder (models/transformer.py:452-456)."""
+        max_len = min(max_len, self.max_len)
+        if beam_size > 1:
+            tokens, lengths, score, attn = self.beam_search_ids(feats, max_len, beam_size, return_attn)
+            tok, ln = tokens.cpu().numpy(), lengths.cpu().numpy()
+            ids = [tok[b, : ln[b]].tolist() for b in range(tok.shape[0])]
+            captions = [vocab.encode_as_words(i) for i in ids]
+            if not return_attn:
+                return captions, score
+            a = attn.cpu().numpy()
+            return captions, score, [[a[b, s] for s in range(ln[b] - 1)] for b in range(len(ids))]
+        tokens, total, attn = self.sample_ids(feats, max_len, temp, return_attn, uniforms)
+        captions = [vocab.encode_as_words(row) for row in tokens.cpu().numpy().tolist()]
+        if not return_attn:
+            return captions, total
+        a = attn.cpu().numpy()
+        return captions, total, [[a[l, s] for s in range(a.shape[1])] for l in range(a.shape[0])]
+
+    @classmethod
+    def from_state_dict(cls, state_dict, vocab, num_heads: int = 2, dtype=torch.bfloat16, device="cuda",
+                        encoder: Optional[str] = None, **kw) -> "ImageCaptioner":
+        if encoder is None:
+            encoder = "resnet50" if "encoder.resnet.0.weight" in state_dict else "none"
+        return cls(vocab, num_heads, dtype, encoder, **kw).load_state_dict(state_dict).to(device)

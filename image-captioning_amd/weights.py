@@ -1,0 +1,283 @@
+"""State-dict -> device weight images for libmic_hip.
+
+Accepts the reference's parameter names (``checkpoint["model_state"]`` written by train.py:390-403,
+loaded by plotter/captions.py:393-396) and lays the tensors out the way the kernels read them:
+K-contiguous ``[out_features padded to 128][K]`` matrices in the compute dtype, eval BatchNorm
+folded into the convolution, fp32 biases / LayerNorm / embedding tables.  Load-time plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+SD = Dict[str, torch.Tensor]
+RESNET50_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))  # width, blocks, stride of first block
+ROW_PAD = 128  # weight rows are padded so any tile of the GEMM kernel may load them unguarded
+
+
+def k_multiple(dtype: torch.dtype) -> int:
+    """K granularity of the GEMM kernel: one 64-byte tile row."""
+    return 64 // torch.empty((), dtype=dtype).element_size()
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class Keep:
+    """Owns the device tensors a ctypes struct points into."""
+
+    def __init__(self):
+        self.tensors: List[torch.Tensor] = []
+
+    def __call__(self, t: torch.Tensor) -> int:
+        self.tensors.append(t)
+        return t.data_ptr()
+
+
+def matrix(w: torch.Tensor, dtype: torch.dtype, device, k_pad: Optional[int] = None) -> torch.Tensor:
+    """[N][K] fp32 -> zero-padded [ceil128(N)][k_pad] in the compute dtype."""
+    n, k = w.shape
+    kp = k_pad or _round_up(k, k_multiple(dtype))
+    out = torch.zeros(_round_up(n, ROW_PAD), kp, dtype=torch.float32)
+    out[:n, :k] = w.float()
+    return out.to(device=device, dtype=dtype).contiguous()
+
+
+def vector(v: torch.Tensor, device) -> torch.Tensor:
+    return v.detach().float().contiguous().to(device)
+
+
+def fold_bn(conv_w: torch.Tensor, g: torch.Tensor, b: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps: float = 1e-5):
+    """conv followed by eval BatchNorm == conv with w*s and bias b - mean*s, s = g/sqrt(var+eps)."""
+    s = g.double() / torch.sqrt(var.double() + eps)
+    return (conv_w.double() * s[:, None, None, None]).float(), (b.double() - mean.double() * s).float()
+
+
+def conv_matrix(w: torch.Tensor, dtype, device) -> torch.Tensor:
+    """(cout,cin,kh,kw) -> [cout padded][kh][kw][cin]: tap-major, channel-contiguous K."""
+    co, ci, kh, kw = w.shape
+    return matrix(w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci), dtype, device)
+
+
+def stem_matrix(w: torch.Tensor, dtype, device) -> torch.Tensor:
+    """(64,3,7,7) -> [128][7 rows][8 pixels][4 channels]; pixel 7 and channel 3 are zero."""
+    co = w.shape[0]
+    m = torch.zeros(co, 7, 8, 4)
+    m[:, :, :7, :3] = w.permute(0, 2, 3, 1).float()
+    return matrix(m.reshape(co, 224), dtype, device)
+
+
+def _conv_layer(keep: Keep, w, bias, dtype, device, stride, pad, relu, stem=False) -> L.ConvLayer:
+    co, ci, kh, kw = w.shape
+    wm = stem_matrix(w, dtype, device) if stem else conv_matrix(w, dtype, device)
+    return L.ConvLayer(keep(wm), keep(vector(bias, device)), ci, co, kh, kw, stride, pad, int(relu))
+
+
+def build_resnet50(sd: SD, prefix: str, dtype: torch.dtype, device) -> tuple:
+    """torchvision resnet50 children 0..7 under ``prefix`` ('encoder.resnet.') -> mic_resnet50."""
+    keep = Keep()
+    net = L.Resnet50()
+    net.dtype = L.dtype_code(dtype)
+
+    def cb(conv: str, bn: str):
+        return fold_bn(sd[conv + ".weight"], sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"], sd[bn + ".running_var"])
+
+    w, b = cb(prefix + "0", prefix + "1")
+    net.stem = _conv_layer(keep, w, b, dtype, device, 2, 3, True, stem=True)
+    bi = 0
+    for si, (width, blocks, stride) in enumerate(RESNET50_STAGES):
+        net.blocks_per_stage[si] = blocks
+        for k in range(blocks):
+            p = f"{prefix}{4 + si}.{k}."
+            s = stride if k == 0 else 1
+            w, b = cb(p + "conv1", p + "bn1")
+            net.conv[bi][0] = _conv_layer(keep, w, b, dtype, device, 1, 0, True)
+            w, b = cb(p + "conv2", p + "bn2")
+            net.conv[bi][1] = _conv_layer(keep, w, b, dtype, device, s, 1, True)
+            w, b = cb(p + "conv3", p + "bn3")
+            net.conv[bi][2] = _conv_layer(keep, w, b, dtype, device, 1, 0, True)  # ReLU after the residual add
+            if (p + "downsample.0.weight") in sd:
+                w, b = cb(p + "downsample.0", p + "downsample.1")
+                net.conv[bi][3] = _conv_layer(keep, w, b, dtype, device, s, 0, False)
+            bi += 1
+    return net, keep
+
+
+def build_tr_decoder(sd: SD, heads: int, dtype: torch.dtype, device) -> tuple:
+    """models/transformer.py parameter names -> mic_tr_decoder."""
+    keep = Keep()
+    dec = L.TrDecoder()
+    tok = sd["seq_embedding.token_embedding.weight"]
+    pos = sd["seq_embedding.pos_embedding.weight"]
+    V, H = tok.shape
+    layers = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("decoder_layers."))
+    if layers > L.MAX_LAYERS:
+        raise ValueError(f"{layers} decoder layers exceed the supported {L.MAX_LAYERS}")
+    if H % heads != 0:
+        raise ValueError(f"hidden size {H} is not divisible by num_heads {heads}")
+    dec.dtype, dec.H, dec.heads, dec.layers, dec.vocab, dec.pos_rows = L.dtype_code(dtype), H, heads, layers, V, pos.shape[0]
+    dec.tok_emb, dec.pos_emb = keep(vector(tok, device)), keep(vector(pos, device))
+    for i in range(layers):
+        p = f"decoder_layers.{i}."
+        Y = dec.layer[i]
+        w, b = sd[p + "self_attention.mha.in_proj_weight"], sd[p + "self_attention.mha.in_proj_bias"]
+        Y.self_in_w, Y.self_in_b = keep(matrix(w, dtype, device)), keep(vector(b, device))
+        Y.self_out_w = keep(matrix(sd[p + "self_attention.mha.out_proj.weight"], dtype, device))
+        Y.self_out_b = keep(vector(sd[p + "self_attention.mha.out_proj.bias"], device))
+        w, b = sd[p + "cross_attention.mha.in_proj_weight"], sd[p + "cross_attention.mha.in_proj_bias"]
+        Y.cross_q_w, Y.cross_q_b = keep(matrix(w[:H], dtype, device)), keep(vector(b[:H], device))
+        Y.cross_kv_w, Y.cross_kv_b = keep(matrix(w[H:], dtype, device)), keep(vector(b[H:], device))
+        Y.cross_out_w = keep(matrix(sd[p + "cross_attention.mha.out_proj.weight"], dtype, device))
+        Y.cross_out_b = keep(vector(sd[p + "cross_attention.mha.out_proj.bias"], device))
+        Y.ff1_w, Y.ff1_b = keep(matrix(sd[p + "ff.seq.0.weight"], dtype, device)), keep(vector(sd[p + "ff.seq.0.bias"], device))
+        Y.ff2_w, Y.ff2_b = keep(matrix(sd[p + "ff.seq.2.weight"], dtype, device)), keep(vector(sd[p + "ff.seq.2.bias"], device))
+        for j, nm in enumerate(("self_attention", "cross_attention", "ff"), start=1):
+            setattr(Y, f"ln{j}_g", keep(vector(sd[p + nm + ".layer_norm.weight"], device)))
+            setattr(Y, f"ln{j}_b", keep(vector(sd[p + nm + ".layer_norm.bias"], device)))
+    dec.out_w = keep(matrix(sd["output_layer.linear.weight"], dtype, device))
+    dec.out_b = keep(vector(sd["output_layer.linear.bias"], device))
+    return dec, keep
+
+
+def build_lstm_decoder(sd: SD, kind: str, dtype: torch.dtype, device) -> tuple:
+    """models/basic.py / models/intermediate.py decoder parameter names -> mic_lstm_decoder."""
+    keep = Keep()
+    dec = L.LstmDecoder()
+    emb = sd["decoder.embed.weight"]
+    V, E = emb.shape
+    Hd = sd["decoder.lstm.weight_hh_l0"].shape[1]
+    layers = 1 + max(int(k.rsplit("_l", 1)[1]) for k in sd if k.startswith("decoder.lstm.weight_ih_l"))
+    if layers > L.MAX_LAYERS:
+        raise ValueError(f"{layers} LSTM layers exceed the supported {L.MAX_LAYERS}")
+    km = k_multiple(dtype)
+    dec.dtype, dec.E, dec.Hd, dec.layers, dec.vocab = L.dtype_code(dtype), E, Hd, layers, V
+    dec.kind = {"basic": 0, "intermediate": 1}[kind]
+    dec.embed = keep(vector(emb, device))
+    for l in range(layers):
+        wi, wh = sd[f"decoder.lstm.weight_ih_l{l}"], sd[f"decoder.lstm.weight_hh_l{l}"]
+        kp = _round_up(wi.shape[1] + Hd, km)
+        dec.kpad[l] = kp
+        dec.w[l] = keep(matrix(torch.cat([wi, wh], dim=1), dtype, device, kp))
+        dec.b[l] = keep(vector(sd[f"decoder.lstm.bias_ih_l{l}"] + sd[f"decoder.lstm.bias_hh_l{l}"], device))
+    if kind == "intermediate":
+        dec.ln_g = keep(vector(sd["decoder.layer_norm.weight"], device))
+        dec.ln_b = keep(vector(sd["decoder.layer_norm.bias"], device))
+    dec.out_k = _round_up(Hd, km)
+    dec.out_w = keep(matrix(sd["decoder.linear.weight"], dtype, device, dec.out_k))
+    dec.out_b = keep(vector(sd["decoder.linear.bias"], device))
+    return dec, keep
+
+
+# --------------------------------------------------------------------------------------------------
+# random initialisation under the reference's names (benchmarks and tests; no checkpoint ships)
+# --------------------------------------------------------------------------------------------------
+def _uniform(g, shape, bound):
+    return (torch.rand(*shape, generator=g) * 2 - 1) * bound
+
+
+def random_resnet50_state(seed: int = 0, prefix: str = "encoder.resnet.") -> SD:
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=g) * math.sqrt(2.0 / (co * k * k))
+
+    def bn(name, c):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_var"] = 1.0 + 0.2 * torch.rand(c, generator=g)
+
+    conv(prefix + "0", 64, 3, 7)
+    bn(prefix + "1", 64)
+    cin = 64
+    for si, (width, blocks, _) in enumerate(RESNET50_STAGES):
+        for k in range(blocks):
+            p = f"{prefix}{4 + si}.{k}."
+            conv(p + "conv1", width, cin, 1); bn(p + "bn1", width)
+            conv(p + "conv2", width, width, 3); bn(p + "bn2", width)
+            conv(p + "conv3", width * 4, width, 1); bn(p + "bn3", width * 4)
+            if k == 0:
+                conv(p + "downsample.0", width * 4, cin, 1); bn(p + "downsample.1", width * 4)
+            cin = width * 4
+    return sd
+
+
+def output_bias_from_counts(counts: Sequence[float], banned=(0, 1, 3)) -> torch.Tensor:
+    """Log-unigram output bias with PAD/SOS/UNK at -1e9 (Output.adapt, models/transformer.py:248-284)."""
+    c = torch.tensor([0.0 if i in banned else float(x) for i, x in enumerate(counts)], dtype=torch.float64)
+    total = float(c.sum())
+    bias = torch.full((len(c),), -1e9, dtype=torch.float32)
+    if total == 0:
+        bias.zero_()
+        bias[list(banned)] = -1e9
+        return bias
+    pos = c > 0
+    bias[pos] = torch.log((c[pos] / total).float())
+    return bias
+
+
+def random_transformer_state(V: int, H: int, layers: int, pos_rows: int, seed: int = 0, counts=None) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {"seq_embedding.token_embedding.weight": torch.randn(V, H, generator=g),
+              "seq_embedding.pos_embedding.weight": torch.randn(pos_rows, H, generator=g)}
+    sd["seq_embedding.token_embedding.weight"][0].zero_()
+    for i in range(layers):
+        p = f"decoder_layers.{i}."
+        for a in ("self_attention", "cross_attention"):
+            sd[p + a + ".mha.in_proj_weight"] = _uniform(g, (3 * H, H), math.sqrt(6.0 / (4 * H)))
+            sd[p + a + ".mha.in_proj_bias"] = torch.zeros(3 * H)
+            sd[p + a + ".mha.out_proj.weight"] = _uniform(g, (H, H), 1 / math.sqrt(H))
+            sd[p + a + ".mha.out_proj.bias"] = torch.zeros(H)
+        sd[p + "ff.seq.0.weight"] = _uniform(g, (2 * H, H), 1 / math.sqrt(H))
+        sd[p + "ff.seq.0.bias"] = _uniform(g, (2 * H,), 1 / math.sqrt(H))
+        sd[p + "ff.seq.2.weight"] = _uniform(g, (H, 2 * H), 1 / math.sqrt(2 * H))
+        sd[p + "ff.seq.2.bias"] = _uniform(g, (H,), 1 / math.sqrt(2 * H))
+        for a in ("self_attention", "cross_attention", "ff"):
+            sd[p + a + ".layer_norm.weight"] = torch.ones(H)
+            sd[p + a + ".layer_norm.bias"] = torch.zeros(H)
+    sd["output_layer.linear.weight"] = _uniform(g, (V, H), 1 / math.sqrt(H))
+    if counts is None:
+        counts = [0, 50, 50, 0] + [(i % 97) + 1 for i in range(4, V)]
+    sd["output_layer.linear.bias"] = output_bias_from_counts(counts)
+    return sd
+
+
+def random_lstm_state(kind: str, V: int, E: int, Hd: int, layers: int, seed: int = 0) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    b = 1 / math.sqrt(Hd)
+    sd: SD = {"decoder.embed.weight": torch.randn(V, E, generator=g)}
+    sd["decoder.embed.weight"][0].zero_()
+    for l in range(layers):
+        ind = E if l == 0 else Hd
+        sd[f"decoder.lstm.weight_ih_l{l}"] = _uniform(g, (4 * Hd, ind), b)
+        sd[f"decoder.lstm.weight_hh_l{l}"] = _uniform(g, (4 * Hd, Hd), b)
+        sd[f"decoder.lstm.bias_ih_l{l}"] = _uniform(g, (4 * Hd,), b)
+        sd[f"decoder.lstm.bias_hh_l{l}"] = _uniform(g, (4 * Hd,), b)
+    sd["decoder.linear.weight"] = _uniform(g, (V, Hd), b)
+    bias = torch.zeros(V)
+    bias[[0, 1, 3]] = -1e9
+    sd["decoder.linear.bias"] = bias
+    if kind == "intermediate":
+        for nm in ("init_h", "init_c"):
+            sd[f"decoder.{nm}.weight"] = _uniform(g, (layers * Hd, E), 1 / math.sqrt(E))
+            sd[f"decoder.{nm}.bias"] = _uniform(g, (layers * Hd,), 1 / math.sqrt(E))
+        sd["decoder.layer_norm.weight"] = torch.ones(Hd)
+        sd["decoder.layer_norm.bias"] = torch.zeros(Hd)
+    return sd
+
+
+def random_head_state(kind: str, out_dim: int, seed: int = 0) -> SD:
+    """Encoder head under the reference's names: projection.0 (transformer), linear.0 (intermediate), linear (basic)."""
+    g = torch.Generator().manual_seed(seed + 17)
+    b = 1 / math.sqrt(2048)
+    if kind == "transformer":
+        return {"encoder.projection.0.weight": _uniform(g, (out_dim, 2048, 1, 1), b), "encoder.projection.0.bias": _uniform(g, (out_dim,), b)}
+    name = "encoder.linear.0" if kind == "intermediate" else "encoder.linear"
+    return {name + ".weight": _uniform(g, (out_dim, 2048), b), name + ".bias": _uniform(g, (out_dim,), b)}

@@ -1,0 +1,308 @@
+/*
+ * libmic_hip — C-ABI of the MI355X (gfx950) caption-generation kernels.
+ *
+ * Drop-in boundary for the generate path of MicaKil/image-captioning: everything
+ * `model.generate(...)` computes between "images on the device" and "token ids +
+ * scores (+ attention) on the device".  The reference has no native code; each entry
+ * point below names the Python it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless the comment says "host";
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *    and nothing is allocated;
+ *  - return value: 0 = ok, MIC_ERR_ARG (-1) = rejected arguments, >0 = hipError_t;
+ *    `mic_last_error()` returns a thread-local message for the last non-zero return;
+ *  - dtype codes select the storage/MFMA type of weights and GEMM inputs: MIC_F32 runs the
+ *    f32-input MFMA (exact fp32 products), MIC_BF16 the bf16 MFMA with fp32 accumulation.
+ *    Residual streams, LayerNorm, softmax, logits, scores stay fp32; beam scores are fp64;
+ *  - activations are NHWC ("pixel-major"): an image-token matrix (B, S, C) is the same bytes.
+ */
+#ifndef MIC_HIP_H
+#define MIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIC_F32 0
+#define MIC_BF16 1
+#define MIC_ERR_ARG (-1)
+
+#define MIC_MAX_BEAM 8      /* beam width accepted by the search kernels */
+#define MIC_MAX_LAYERS 8    /* decoder depth accepted by the step drivers (sweeper/config.py:80 tops out at 6) */
+
+const char* mic_last_error(void);
+int mic_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder building blocks (models/encoders/ -> torchvision resnet50 children)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Implicit-GEMM convolution / linear layer on the matrix cores:
+ *   out[m, n] = act( sum_k A[m, k] * W[n, k] + bias[n] + res[m, n] )
+ * m enumerates output pixels (b, oh, ow); k enumerates (tap, c) with `run` contiguous input
+ * elements per tap, tap = kh * kw_taps + kw read at input pixel (oh*stride - pad_h + kh,
+ * ow*stride - pad_w + kw) (zero outside [0,IH)x[0,IW)).  A linear layer is the 1x1 case with
+ * OH = OW = IH = IW = 1 and in_img_stride = the row stride of the input matrix.
+ * Replaces nn.Conv2d + eval BatchNorm2d (folded into W/bias by the host) + ReLU + the bottleneck
+ * residual add (torchvision Bottleneck.forward, reached from models/encoders/transformer.py:46),
+ * the 1x1 projection (models/encoders/transformer.py:33-37,47) and every nn.Linear on the path
+ * (models/transformer.py:83,136,175,293; models/intermediate.py:55-56,66; models/basic.py:49).
+ * Requirements: K = taps*run, run % (64/sizeof(T)) == 0, W has n_pad >= ceil(N/128)*128 rows of K
+ * elements (rows >= N zero), all base pointers 16-byte aligned. */
+typedef struct mic_conv_desc {
+    const void* in;       /* T, NHWC */
+    const void* w;        /* T, [n_pad][K] */
+    const float* bias;    /* fp32 [N] or NULL */
+    const void* res;      /* residual [M][ld_res] of res_dtype, or NULL */
+    void* out;            /* [M][ldc] of out_dtype */
+    int32_t dtype;        /* MIC_F32 / MIC_BF16: type of in and w */
+    int32_t out_dtype, res_dtype;
+    int32_t M, N, K;
+    int32_t OH, OW, IH, IW;
+    int64_t in_img_stride, in_row_stride; /* elements */
+    int32_t in_pix_stride;
+    int32_t kw_taps, run;
+    int32_t stride, pad_h, pad_w;
+    int32_t ldc, ld_res;
+    int32_t relu;
+} mic_conv_desc;
+int mic_conv2d(const mic_conv_desc* d, void* stream);
+
+/* (B,3,H,W) fp32 planar image -> zero-bordered 4-channel pixel-major image
+ * out[B][H+pad_t+pad_b][W+pad_l+pad_r][4] of `dtype` (channel 3 = 0).  Input staging for the
+ * 7x7/2 stem, which then reads each kernel row as one contiguous 32-element run.
+ * Replaces the tensor handed to resnet conv1 (models/encoders/transformer.py:46). */
+int mic_pack_image(const float* nchw, void* out, int dtype, int B, int H, int W,
+                   int pad_t, int pad_b, int pad_l, int pad_r, void* stream);
+
+/* 3x3 stride-2 pad-1 max pooling, NHWC (torchvision resnet50 child 3, nn.MaxPool2d(3,2,1)). */
+int mic_maxpool3x3s2(const void* in, void* out, int dtype, int B, int H, int W, int C, void* stream);
+
+/* Global average pooling NHWC (B,HW,C) -> (B,C) (torchvision resnet50 child 8,
+ * AdaptiveAvgPool2d(1), kept by models/encoders/intermediate.py:27-28 and basic.py:25-26).
+ * ld_out is the row stride of out in elements. */
+int mic_global_avgpool(const void* in, void* out, int dtype, int B, int HW, int C, int ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder step building blocks
+ * ---------------------------------------------------------------------------------------- */
+
+/* x[n,:] = tok_emb[ids[n*ld_ids + pos]] + pos_emb[pos]; writes fp32 x and (if xt != NULL) a copy in
+ * `dtype` with row stride ld_xt.  pos_emb == NULL gives a plain embedding gather (LSTM decoders).
+ * Replaces SeqEmbedding.forward (models/transformer.py:44-50) for the newest position and
+ * nn.Embedding in models/basic.py:43, models/intermediate.py:59. */
+int mic_embed_pos(const int32_t* ids, int ld_ids, int pos, const float* tok_emb, const float* pos_emb,
+                  float* x, void* xt, int ld_xt, int dtype, int N, int H, int vocab, void* stream);
+
+/* Row LayerNorm (eps 1e-5): y = LN(x) * gamma + beta; writes fp32 y (may alias x) and optional
+ * `dtype` copy yt (row stride ld_yt).  nn.LayerNorm at models/transformer.py:86,140,177 and
+ * models/intermediate.py:64. */
+int mic_layernorm(const float* x, const float* gamma, const float* beta, float* y, void* yt, int ld_yt,
+                  int dtype, int N, int H, void* stream);
+
+/* One new query per row against that row's cached keys/values, all heads
+ * (the attention inside nn.MultiheadAttention, torch/nn/functional.py:6578-6606, for the last
+ * text position only; the rest of the prefix is what the cache holds).
+ *  self form  (models/transformer.py:83): qkv fp32 [N][3H] = packed in-proj output for position t.
+ *      k,v of position t are appended to kcache/vcache [N][t_cap][H] (`dtype`), and positions
+ *      p < t are read from row anc[n*t_cap + p] (beam ancestry; anc == NULL reads row n).
+ *  cross form (models/transformer.py:136): q fp32 [N][ldq]; keys/values of row n are
+ *      kv[(n / rows_per_image)][S][2H] (`dtype`, k then v).  If attn_out != NULL the head-averaged
+ *      weights (N,S) are written as attn_out = (accumulate ? attn_out : 0) + attn_scale * w.
+ * Output o [N][ld_o] in `dtype` (input of the out-projection GEMM). */
+int mic_self_attn_step(const float* qkv, void* kcache, void* vcache, const int32_t* anc, int t, int t_cap,
+                       void* o, int ld_o, int dtype, int N, int H, int heads, void* stream);
+int mic_cross_attn_step(const float* q, int ldq, const void* kv, int S, int rows_per_image,
+                        void* o, int ld_o, float* attn_out, int ld_attn, float attn_scale, int accumulate,
+                        int dtype, int N, int H, int heads, void* stream);
+
+/* LSTM cell pointwise part, gate order i,f,g,o (nn.LSTM, models/basic.py:48,
+ * models/intermediate.py:63): c' = s(f)*c + s(i)*tanh(g); h' = s(o)*tanh(c').  gates fp32
+ * [N][4*Hd]; c, h fp32 [N][Hd] updated in place; h' is also written in `dtype` to ht0 (row stride
+ * ld0) and ht1 (row stride ld1) when non-NULL: the recurrent half of this layer's next GEMM input
+ * and the input half of the layer above. */
+int mic_lstm_cell(const float* gates, float* c, float* h, void* ht0, int ld0, void* ht1, int ld1,
+                  int dtype, int N, int Hd, void* stream);
+
+/* dst[r,:] = src[idx[r],:] for `rows` rows of `row_bytes` bytes (multiple of 4):
+ * beam reorder of per-beam recurrent state (the list slicing at models/image_captioner.py:148-149). */
+int mic_gather_rows(const void* src, void* dst, const int32_t* idx, int rows, int row_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Search kernels
+ * ---------------------------------------------------------------------------------------- */
+
+/* Per row: lp = log_softmax(logits * inv_temp) and its K largest entries, largest first, ties to
+ * the lower index.  rank_raw != 0 ranks by the raw logits instead of lp (argmax of logits,
+ * models/image_captioner.py:92).  Replaces F.log_softmax + topk/argmax
+ * (models/transformer.py:516,526,610,615; models/image_captioner.py:138-139).
+ * out_val fp32 [N][K], out_idx int32 [N][K]; lse (optional) fp32 [N] = max + log(sum exp). */
+int mic_logsoftmax_topk(const float* logits, int ld, int N, int V, int K, float inv_temp, int rank_raw,
+                        float* out_val, int32_t* out_idx, float* lse, void* stream);
+
+/* Inverse-CDF draw from softmax(logits*inv_temp) with caller-supplied uniforms u[N]: first index
+ * whose running fp32 sum of probabilities exceeds u.  Writes the index and its log-probability.
+ * Stands in for torch.multinomial (models/transformer.py:521-522, models/image_captioner.py:94-95),
+ * whose random stream cannot be reproduced on the device. */
+int mic_sample_multinomial(const float* logits, int ld, int N, int V, float inv_temp, const float* u,
+                           float* out_val, int32_t* out_idx, void* stream);
+
+/* Beam state of B images x K slots.  seq/anc are [B*K][t_cap] int32; score fp64; len int32. */
+typedef struct mic_beam_state {
+    double* score;
+    int32_t* len;
+    int32_t* seq;
+    int32_t* anc;     /* may be NULL (LSTM path keeps no ancestry) */
+} mic_beam_state;
+
+/* One beam-search selection step for every image (models/transformer.py:613-628 when
+ * finished_in_place == 0, models/image_captioner.py:128-149 when 1): extend each live slot by its K
+ * best tokens (top_val/top_idx [B*K][K]), pool with finished slots, stable-sort by
+ * score / sqrt_tab[len] descending (fp64; sqrt_tab[i] = i ** 0.5 computed by the host), keep K.
+ * Only the first n_live_slots slots of `cur` are considered (1 at the first step).  Writes `nxt`,
+ * parent[B*K] (slot each survivor came from) and adds the number of images that still have a live
+ * beam to *live_images (caller zeroes it). */
+int mic_beam_select(const mic_beam_state* cur, const mic_beam_state* nxt, const float* top_val,
+                    const int32_t* top_idx, int32_t* parent, int32_t* live_images,
+                    const double* sqrt_tab, int B, int K, int n_live_slots, int t, int t_cap,
+                    int eos_id, int finished_in_place, void* stream);
+
+/* Best beam per image (first maximum of score/sqrt(len), models/transformer.py:635-638):
+ * tokens [B][t_cap] (-1 padded), lengths [B], score fp32 [B]; if attn_hist != NULL
+ * ([B*K][t_cap][S], per-position layer-averaged weights) also attn_out [B][t_cap][S] with
+ * attn_out[b][s] = mean over p <= s of hist[anc[best][p]][p] (models/transformer.py:606-611,620). */
+int mic_beam_finalize(const mic_beam_state* st, const double* sqrt_tab, int B, int K, int t_cap,
+                      int32_t* tokens, int32_t* lengths, float* score, const float* attn_hist, int S,
+                      float* attn_out, void* stream);
+
+/* Greedy / sampling bookkeeping for one step (models/transformer.py:530-543,
+ * models/image_captioner.py:98-102): total += finished ? 0 : val; tok = finished ? pad : idx;
+ * tokens[n*t_cap + pos] = tok; finished |= tok == eos; adds the number of unfinished rows to
+ * *live_rows (caller zeroes it). */
+int mic_sample_update(const float* val, const int32_t* idx, int32_t* tokens, int t_cap, int pos,
+                      uint8_t* finished, float* total, int32_t* live_rows, int N, int pad_id, int eos_id,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-path drivers: the same kernels chained natively so the host issues one call per phase.
+ * ---------------------------------------------------------------------------------------- */
+
+/* ResNet-50 trunk (+ optional max-pool'd stem) as a list of fused conv layers.  The host fills one
+ * mic_conv_layer per convolution (BN folded); the driver fixes up pointers and shapes per batch. */
+typedef struct mic_conv_layer {
+    const void* w;
+    const float* bias;
+    int32_t cin, cout, kh, kw, stride, pad, relu;
+} mic_conv_layer;
+
+typedef struct mic_resnet50 {
+    int32_t dtype;
+    mic_conv_layer stem;            /* 7x7/2 as 7 row-taps of 32 over the packed image */
+    int32_t blocks_per_stage[4];
+    mic_conv_layer conv[16][4];     /* per bottleneck: conv1, conv2, conv3, downsample (cout==0: none) */
+} mic_resnet50;
+
+/* Bytes of workspace mic_resnet50_forward needs for a batch. */
+int64_t mic_resnet50_workspace_bytes(const mic_resnet50* net, int B, int H, int W);
+/* images fp32 (B,3,H,W) -> out [B][H/32*W/32][2048] in net->dtype.
+ * torchvision resnet50 children[:-2] as used by models/encoders/transformer.py:24-28,46. */
+int mic_resnet50_forward(const mic_resnet50* net, const float* images, int B, int H, int W,
+                         void* workspace, int64_t workspace_bytes, void* out, void* stream);
+
+typedef struct mic_tr_layer {
+    const void *self_in_w, *self_out_w, *cross_q_w, *cross_kv_w, *cross_out_w, *ff1_w, *ff2_w; /* dtype, padded */
+    const float *self_in_b, *self_out_b, *cross_q_b, *cross_kv_b, *cross_out_b, *ff1_b, *ff2_b;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+} mic_tr_layer;
+
+typedef struct mic_tr_decoder {
+    int32_t dtype, H, heads, layers, vocab, pos_rows;
+    const float* tok_emb;  /* fp32 [vocab][H] */
+    const float* pos_emb;  /* fp32 [pos_rows][H] */
+    mic_tr_layer layer[MIC_MAX_LAYERS];
+    const void* out_w;     /* dtype [vocab padded][H] */
+    const float* out_b;
+} mic_tr_decoder;
+
+/* Per-call decode workspace; every pointer is caller-allocated device memory of at least the
+ * stated size (rows N = B * K, K = 1 for greedy / sampling). */
+typedef struct mic_tr_workspace {
+    int32_t N, t_cap, S, rows_per_image;
+    float* x;        /* [N][H] residual stream */
+    void* xt;        /* [N][H] dtype copy */
+    float* y;        /* [N][H] */
+    float* qkv;      /* [N][3H] */
+    void* o;         /* [N][H] dtype */
+    void* ffh;       /* [N][2H] dtype */
+    float* logits;   /* [N][vocab] */
+    void* kcache[MIC_MAX_LAYERS];   /* [N][t_cap][H] dtype */
+    void* vcache[MIC_MAX_LAYERS];
+    void* cross_kv[MIC_MAX_LAYERS]; /* [N/rows_per_image][S][2H] dtype */
+    float* attn;     /* NULL, or beam: [N][t_cap][S]; sampling: [layers][t_cap][N][S] */
+    float* top_val;  /* [N][K] */
+    int32_t* top_idx;
+} mic_tr_workspace;
+
+/* Cross-attention keys/values of every layer from image tokens feats [B][S][H] (dtype):
+ * the k/v thirds of cross_attention.mha.in_proj applied once per image instead of once per
+ * beam per step (models/transformer.py:136 via :605). */
+int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const void* feats, void* stream);
+
+/* One decoder step for position t: embedding of tokens[n*ld_tok + t], every layer, vocabulary
+ * projection into ws->logits (models/transformer.py:602-609 / :492-507 for the newest position).
+ * anc: beam ancestry [N][t_cap] or NULL.  attn_mode: 0 none, 1 beam layout, 2 sampling layout. */
+int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
+                const int32_t* anc, int t, int attn_mode, void* stream);
+
+/* Steps [t0, t1) of transformer beam search on device: mic_tr_step, log-softmax top-K, beam
+ * selection, ping-ponging between st[0] and st[1] (st[t & 1] is current at step t).
+ * live_images: int32[t_cap] device counters, entry t receives the number of images with a live beam
+ * after step t.  models/transformer.py:589-632. */
+int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const mic_beam_state st[2],
+                      int32_t* parent, int32_t* live_images, const double* sqrt_tab, int B, int K,
+                      int t0, int t1, int eos_id, int want_attn, void* stream);
+
+/* Steps [t0, t1) of batched greedy (u == NULL) or temperature sampling (u = uniforms [t_cap][N]).
+ * models/transformer.py:490-547. */
+int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, int32_t* tokens,
+                        uint8_t* finished, float* total, int32_t* live_rows, float inv_temp, const float* u,
+                        int t0, int t1, int pad_id, int eos_id, int want_attn, void* stream);
+
+typedef struct mic_lstm_decoder {
+    int32_t dtype, E, Hd, layers, vocab, kind; /* kind 0 = basic, 1 = intermediate */
+    int32_t kpad[MIC_MAX_LAYERS];              /* padded K = in_dim + Hd of each layer's GEMM */
+    const float* embed;                        /* fp32 [vocab][E] */
+    const void* w[MIC_MAX_LAYERS];             /* dtype [4Hd padded][kpad]: [W_ih | W_hh] */
+    const float* b[MIC_MAX_LAYERS];            /* fp32 [4Hd] = b_ih + b_hh */
+    const float *ln_g, *ln_b;                  /* intermediate only */
+    const void* out_w;                         /* dtype [vocab padded][Hd padded] */
+    const float* out_b;
+    int32_t out_k;                             /* padded K of the vocabulary GEMM */
+} mic_lstm_decoder;
+
+typedef struct mic_lstm_workspace {
+    int32_t N;
+    void* xh[MIC_MAX_LAYERS];   /* [N][kpad] dtype: [layer input | h] */
+    float* h[MIC_MAX_LAYERS];   /* [N][Hd] */
+    float* c[MIC_MAX_LAYERS];
+    float* gates;               /* [N][4Hd] */
+    float* hn;                  /* [N][Hd] LayerNorm output */
+    void* hnt;                  /* [N][out_k] dtype */
+    float* logits;              /* [N][vocab] */
+    float* scratch;             /* [N][max(E,Hd)] fp32 */
+} mic_lstm_workspace;
+
+/* One LSTM decoder step (all layers + LayerNorm (intermediate) + vocabulary projection) from the
+ * carried (h, c).  If feat_t != NULL the layer-0 input is that row of image features (dtype,
+ * [N][ld_feat]) instead of an embedded token: time-step 0 of models/basic.py:45-48.  Otherwise the
+ * input is embed[tokens[n*ld_tok + pos]].  models/intermediate.py:59-66. */
+int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, const int32_t* tokens, int ld_tok,
+                  int pos, const void* feat_t, int ld_feat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIC_HIP_H */
