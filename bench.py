@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images captioned / second, transformer captioner (ResNet-50 encoder +
+3-layer transformer decoder, H=512, 2 heads, V=3500), beam=3, max_len=30, 224x224 synthetic
+images, batch 256 per GPU, bf16 weights/GEMM inputs with fp32 accumulation.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one whole generate call (encoder + cross-K/V + 30 beam-search steps + best-beam
+extraction) over one batch of 256 images that already sit in HBM, followed by the gather of token
+ids across ranks.  String detokenisation is excluded (the metric is defined on token ids).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH, IMG, MAX_LEN, BEAM = 256, 224, 30, 3
+V, H, LAYERS, HEADS, POS_ROWS = 3500, 512, 3, 2, 40
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X
+
+
+def build_state():
+    import image_captioning_amd as amd
+    sd = amd.weights.random_resnet50_state(0)
+    sd.update(amd.weights.random_head_state("transformer", H, 0))
+    sd.update(amd.weights.random_transformer_state(V, H, LAYERS, POS_ROWS, seed=0))
+    return sd
+
+
+def cpu_baseline(sd, n_images: int):
+    """The oracle (reference-as-written search, fp32 PyTorch-CPU) on the first images of the same
+    synthetic workload, timed on this host's cores."""
+    import torch
+    from oracle import captioner_oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    img = torch.randn(n_images, 3, IMG, IMG, generator=torch.Generator().manual_seed(1234))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        feats = O.encoder_transformer(sd, img)
+        O.transformer_generate(sd, HEADS, feats, MAX_LEN, None, BEAM)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_images / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n_images} images of the same workload (ResNet-50 + per-image beam={BEAM} search with full-prefix "
+                      f"recompute, fp32 torch CPU), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
+    ap.add_argument("--cpu-images", type=int, default=12, help="sample size of the CPU baseline (0 disables it)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: start one rank per GPU as child processes and pass their exit code on
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
+    import torch
+    import torch.distributed as dist
+    import image_captioning_amd as amd
+    from image_captioning_amd import distributed as D
+
+    rank, local, world = D.init_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    L = amd._lib
+
+    sd = build_state()
+    vocab = amd.Vocabulary.synthetic(V)
+    model = amd.transformer.ImageCaptioner(vocab, HEADS, torch.bfloat16, sync_every=MAX_LEN).load_state_dict(sd).to(dev)
+    B = args.batch
+    images = torch.randn(B, 3, IMG, IMG, generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev)
+    n_total = B * world
+
+    def step():
+        feats = model.encode(images)
+        tokens, lengths, score, _ = model.beam_search_ids(feats, MAX_LEN, BEAM)
+        return D.gather_captions(tokens, lengths, score, n_total)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    L.check(L.lib.mic_profile_begin(max(1, args.steps) * 1200), "mic_profile_begin")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    cnt, ms, fl = (C.c_int32 * 4)(), (C.c_double * 4)(), (C.c_double * 4)()
+    L.check(L.lib.mic_profile_end(cnt, ms, fl), "mic_profile_end")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    executed_steps = int(out[1].max().item()) - 1  # generated tokens of the longest caption
+
+    if rank == 0:
+        # dominant kernel: igemm_kernel<bf16,128,128> (slot 1), the encoder's implicit-GEMM convolutions
+        k_ms, k_n, k_fl = ms[1], cnt[1], fl[1]
+        achieved = (k_fl / k_n) / (k_ms / k_n * 1e-3) / 1e12 if k_n else 0.0
+        res = {
+            "metric": "images captioned/sec (224^2, beam=3, max_len=30)", "value": round(n_total * args.steps / elapsed, 2),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[2]: ResNet-50 encoder + 3-layer transformer decoder (H=512, 2 heads, V=3500), beam=3, "
+                                   "max_len=30, 224x224, batch 256 per GPU, bf16; random-init weights",
+                       "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16,128,128>", "achieved": round(achieved, 2),
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "traffic": None, "launches_per_step": k_n // max(1, args.steps),
+                         "avg_launch_us": round(k_ms / k_n * 1e3, 2) if k_n else None,
+                         "gflop_per_launch": round(k_fl / k_n / 1e9, 3) if k_n else None,
+                         "other_gemm_launches": {"igemm<bf16,64,64>": {"n": cnt[3], "ms": round(ms[3], 3), "tflops": round(fl[3] / (ms[3] * 1e-3) / 1e12, 2) if ms[3] else None}}},
+        }
+        if args.cpu_images > 0 and world == 1:
+            res["cpu_baseline"] = cpu_baseline(sd, args.cpu_images)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
                 ("in_img_stride", i64), ("in_row_stride", i64),
                 ("in_pix_stride", i32), ("kw_taps", i32), ("run", i32),
                 ("stride", i32), ("pad_h", i32), ("pad_w", i32),
-                ("ldc", i32), ("ld_res", i32), ("relu", i32)]
+                ("ldc", i32), ("ld_res", i32), ("relu", i32), ("k_valid", i32)]
 
 
 class BeamState(C.Structure):
@@ -79,6 +79,8 @@ SIGNATURES = {
     "mic_last_error": (C.c_char_p, []),
     "mic_version": (C.c_int, []),
     "mic_conv2d": (C.c_int, [P(ConvDesc), vp]),
+    "mic_profile_begin": (C.c_int, [C.c_int]),
+    "mic_profile_end": (C.c_int, [P(i32), P(C.c_double), P(C.c_double)]),
     "mic_pack_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_global_avgpool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -227,8 +227,7 @@ template <typename T, bool SELF> int launch_attn(const AttnArgs& a, hipStream_t 
     const int npg = 256 / C > 0 ? 256 / C : 1;
     const size_t lds = sizeof(float) * ((size_t)a.H + ((a.heads * P + 3) & ~3) + (size_t)npg * a.H) + sizeof(int) * (SELF ? P : 0);
     MIC_ARG_CHECK(lds <= 64 * 1024, "attention step: %zu bytes of LDS needed (H=%d heads=%d positions=%d)", lds, a.H, a.heads, P);
-    hipLaunchKernelGGL((attn_step_kernel<T, SELF>), dim3(a.N), dim3(256), lds, s, a);
-    MIC_LAUNCH_CHECK();
+    MIC_LAUNCH((attn_step_kernel<T, SELF>), dim3(a.N), dim3(256), lds, s, a);
     return 0;
 }
 
@@ -279,10 +278,9 @@ extern "C" int mic_embed_pos(const int32_t* ids, int ld_ids, int pos, const floa
     const int total = N * (H / 4);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MIC_BF16)
-        hipLaunchKernelGGL(embed_pos_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, ids, ld_ids, pos, tok_emb, pos_emb, x, (bf16_t*)xt, ld_xt, N, H, vocab);
+        MIC_LAUNCH(embed_pos_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, ids, ld_ids, pos, tok_emb, pos_emb, x, (bf16_t*)xt, ld_xt, N, H, vocab);
     else
-        hipLaunchKernelGGL(embed_pos_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, ids, ld_ids, pos, tok_emb, pos_emb, x, (float*)xt, ld_xt, N, H, vocab);
-    MIC_LAUNCH_CHECK();
+        MIC_LAUNCH(embed_pos_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, ids, ld_ids, pos, tok_emb, pos_emb, x, (float*)xt, ld_xt, N, H, vocab);
     return 0;
 }
 
@@ -293,10 +291,9 @@ extern "C" int mic_layernorm(const float* x, const float* gamma, const float* be
     MIC_ARG_CHECK(dtype == MIC_F32 || dtype == MIC_BF16, "mic_layernorm: bad dtype %d", dtype);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MIC_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, y, (bf16_t*)yt, ld_yt, N, H);
+        MIC_LAUNCH(layernorm_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, y, (bf16_t*)yt, ld_yt, N, H);
     else
-        hipLaunchKernelGGL(layernorm_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, y, (float*)yt, ld_yt, N, H);
-    MIC_LAUNCH_CHECK();
+        MIC_LAUNCH(layernorm_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, y, (float*)yt, ld_yt, N, H);
     return 0;
 }
 
@@ -334,10 +331,9 @@ extern "C" int mic_lstm_cell(const float* gates, float* c, float* h, void* ht0, 
     const int total = N * Hd;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MIC_BF16)
-        hipLaunchKernelGGL(lstm_cell_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, gates, c, h, (bf16_t*)ht0, ld0, (bf16_t*)ht1, ld1, N, Hd);
+        MIC_LAUNCH(lstm_cell_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, gates, c, h, (bf16_t*)ht0, ld0, (bf16_t*)ht1, ld1, N, Hd);
     else
-        hipLaunchKernelGGL(lstm_cell_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, gates, c, h, (float*)ht0, ld0, (float*)ht1, ld1, N, Hd);
-    MIC_LAUNCH_CHECK();
+        MIC_LAUNCH(lstm_cell_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, gates, c, h, (float*)ht0, ld0, (float*)ht1, ld1, N, Hd);
     return 0;
 }
 
@@ -347,7 +343,6 @@ extern "C" int mic_gather_rows(const void* src, void* dst, const int32_t* idx, i
     const long long total = (long long)rows * (row_bytes / 4);
     long long g = (total + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, (uint32_t*)dst, idx, rows, row_bytes / 4);
-    MIC_LAUNCH_CHECK();
+    MIC_LAUNCH(gather_rows_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, (uint32_t*)dst, idx, rows, row_bytes / 4);
     return 0;
 }

@@ -93,7 +93,7 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
         d.OH = p.H1; d.OW = p.W1; d.IH = p.Hp; d.IW = p.Wp;
         d.in_img_stride = (int64_t)p.Hp * p.Wp * 4; d.in_row_stride = (int64_t)p.Wp * 4; d.in_pix_stride = 4;
         d.kw_taps = 1; d.run = 32; d.stride = 2; d.pad_h = d.pad_w = 0;
-        d.ldc = 64; d.relu = 1;
+        d.ldc = 64; d.relu = 1; d.k_valid = 7 * 7 * 3;
         MIC_TRY(mic_conv2d(&d, s));
     }
     MIC_TRY(mic_maxpool3x3s2(X[1], X[0], dt, B, p.H1, p.W1, 64, s));

@@ -13,6 +13,9 @@
 // before the MFMAs of tile k and written to the other LDS buffer after them; one barrier per tile.
 #include "mic_common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace {
 
 struct IgemmArgs {
@@ -238,19 +241,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
 }
 
-template <typename T, int BM, int BN> int launch(IgemmArgs& a, hipStream_t s) {
+// ---- optional per-launch event timing (mic_profile_begin / mic_profile_end) ----
+struct ProfRec {
+    hipEvent_t e0, e1;
+    int slot;
+    double flops;
+};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+size_t g_prof_used = 0;
+bool g_prof_on = false;
+
+template <typename T, int BM, int BN> int launch(IgemmArgs& a, hipStream_t s, double flops) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     const int grid = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), 0, s, a);
-    MIC_LAUNCH_CHECK();
+    ProfRec* rec = nullptr;
+    if (g_prof_on) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_on && g_prof_used < g_prof.size()) {
+            rec = &g_prof[g_prof_used++];
+            rec->slot = (BM == 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0);
+            rec->flops = flops;
+        }
+    }
+    if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e0, s));
+    MIC_LAUNCH((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), 0, s, a);
+    if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e1, s));
     return 0;
 }
 
-template <typename T> int dispatch(IgemmArgs& a, hipStream_t s) {
+template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (t128 >= 192) return launch<T, 128, 128>(a, s);
-    return launch<T, 64, 64>(a, s);
+    if (t128 >= 192) return launch<T, 128, 128>(a, s, flops);
+    return launch<T, 64, 64>(a, s, flops);
 }
 
 }  // namespace
@@ -287,5 +311,37 @@ extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
     a.vec_ok = (d->ldc % 4 == 0) && (((uintptr_t)d->out) % (4 * osz) == 0) &&
                (!d->res || (d->ld_res % 4 == 0 && ((uintptr_t)d->res) % 16 == 0));
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == MIC_BF16 ? dispatch<bf16_t>(a, s) : dispatch<float>(a, s);
+    const double flops = 2.0 * d->M * d->N * (d->k_valid > 0 ? d->k_valid : d->K);
+    return d->dtype == MIC_BF16 ? dispatch<bf16_t>(a, s, flops) : dispatch<float>(a, s, flops);
+}
+
+extern "C" int mic_profile_begin(int max_launches) {
+    MIC_ARG_CHECK(max_launches > 0 && max_launches <= (1 << 20), "mic_profile_begin: max_launches=%d", max_launches);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    while (g_prof.size() < (size_t)max_launches) {
+        ProfRec r{};
+        MIC_HIP_CHECK(hipEventCreate(&r.e0));
+        MIC_HIP_CHECK(hipEventCreate(&r.e1));
+        g_prof.push_back(r);
+    }
+    g_prof_used = 0;
+    g_prof_on = true;
+    return 0;
+}
+
+extern "C" int mic_profile_end(int32_t count[4], double ms[4], double flops[4]) {
+    MIC_ARG_CHECK(count && ms && flops, "mic_profile_end: null pointer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    for (int i = 0; i < 4; ++i) { count[i] = 0; ms[i] = 0.0; flops[i] = 0.0; }
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        ProfRec& r = g_prof[i];
+        MIC_HIP_CHECK(hipEventSynchronize(r.e1));
+        float t = 0.f;
+        MIC_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+        const int v = r.slot;  // 2 * (tile variant) + (bf16)
+        count[v] += 1; ms[v] += t; flops[v] += r.flops;
+    }
+    g_prof_used = 0;
+    return 0;
 }

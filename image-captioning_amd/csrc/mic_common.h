@@ -29,7 +29,14 @@ void mic_set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
-#define MIC_LAUNCH_CHECK() MIC_HIP_CHECK(hipGetLastError())
+// hipGetLastError() reports the last error of ANY earlier runtime call on this thread (also other
+// libraries'), so clear it before a launch and read it right after.
+#define MIC_LAUNCH(kernel, grid, block, lds, stream, ...)                        \
+    do {                                                                         \
+        (void)hipGetLastError();                                                 \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);       \
+        MIC_HIP_CHECK(hipGetLastError());                                        \
+    } while (0)
 
 #define MIC_TRY(expr)            \
     do {                         \

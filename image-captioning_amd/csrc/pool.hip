@@ -103,10 +103,9 @@ extern "C" int mic_pack_image(const float* nchw, void* out, int dtype, int B, in
     const long long total = (long long)B * Hp * Wp;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MIC_BF16)
-        hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, nchw, (bf16_t*)out, B, H, W, Hp, Wp, pad_t, pad_l);
+        MIC_LAUNCH(pack_image_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, nchw, (bf16_t*)out, B, H, W, Hp, Wp, pad_t, pad_l);
     else
-        hipLaunchKernelGGL(pack_image_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, nchw, (float*)out, B, H, W, Hp, Wp, pad_t, pad_l);
-    MIC_LAUNCH_CHECK();
+        MIC_LAUNCH(pack_image_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, nchw, (float*)out, B, H, W, Hp, Wp, pad_t, pad_l);
     return 0;
 }
 
@@ -119,10 +118,9 @@ extern "C" int mic_maxpool3x3s2(const void* in, void* out, int dtype, int B, int
     const long long total = (long long)B * OH * OW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MIC_BF16)
-        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, B, H, W, C, OH, OW);
+        MIC_LAUNCH(maxpool_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, B, H, W, C, OH, OW);
     else
-        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C, OH, OW);
-    MIC_LAUNCH_CHECK();
+        MIC_LAUNCH(maxpool_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C, OH, OW);
     return 0;
 }
 
@@ -134,9 +132,8 @@ extern "C" int mic_global_avgpool(const void* in, void* out, int dtype, int B, i
     const int total = B * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MIC_BF16)
-        hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, B, HW, C, ld_out);
+        MIC_LAUNCH(avgpool_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, B, HW, C, ld_out);
     else
-        hipLaunchKernelGGL(avgpool_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)in, (float*)out, B, HW, C, ld_out);
-    MIC_LAUNCH_CHECK();
+        MIC_LAUNCH(avgpool_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)in, (float*)out, B, HW, C, ld_out);
     return 0;
 }

@@ -312,7 +312,7 @@ extern "C" int mic_logsoftmax_topk(const float* logits, int ld, int N, int V, in
     hipStream_t s = (hipStream_t)stream;
 #define MIC_TOPK_CASE(KK)                                                                                                  \
     case KK:                                                                                                               \
-        hipLaunchKernelGGL(logsoftmax_topk_kernel<KK>, dim3(N), dim3(256), 0, s, logits, ld, V, inv_temp, rank_raw, out_val, \
+        MIC_LAUNCH(logsoftmax_topk_kernel<KK>, dim3(N), dim3(256), 0, s, logits, ld, V, inv_temp, rank_raw, out_val, \
                            out_idx, lse);                                                                                  \
         break;
     switch (K) {
@@ -320,7 +320,6 @@ extern "C" int mic_logsoftmax_topk(const float* logits, int ld, int N, int V, in
         MIC_TOPK_CASE(5) MIC_TOPK_CASE(6) MIC_TOPK_CASE(7) MIC_TOPK_CASE(8)
     }
 #undef MIC_TOPK_CASE
-    MIC_LAUNCH_CHECK();
     return 0;
 }
 
@@ -328,8 +327,7 @@ extern "C" int mic_sample_multinomial(const float* logits, int ld, int N, int V,
                                       int32_t* out_idx, void* stream) {
     MIC_ARG_CHECK(logits && u && out_val && out_idx, "mic_sample_multinomial: null pointer");
     MIC_ARG_CHECK(N > 0 && V > 0 && ld >= V, "mic_sample_multinomial: bad sizes N=%d V=%d ld=%d", N, V, ld);
-    hipLaunchKernelGGL(sample_multinomial_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, ld, V, inv_temp, u, out_val, out_idx);
-    MIC_LAUNCH_CHECK();
+    MIC_LAUNCH(sample_multinomial_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, ld, V, inv_temp, u, out_val, out_idx);
     return 0;
 }
 
@@ -346,8 +344,7 @@ extern "C" int mic_beam_select(const mic_beam_state* cur, const mic_beam_state* 
     a.cur = *cur; a.nxt = *nxt; a.top_val = top_val; a.top_idx = top_idx; a.parent = parent; a.live_images = live_images;
     a.sqrt_tab = sqrt_tab; a.B = B; a.K = K; a.n_live_slots = n_live_slots; a.t = t; a.t_cap = t_cap; a.eos_id = eos_id;
     a.in_place = finished_in_place;
-    hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
-    MIC_LAUNCH_CHECK();
+    MIC_LAUNCH(beam_select_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
     return 0;
 }
 
@@ -356,9 +353,8 @@ extern "C" int mic_beam_finalize(const mic_beam_state* st, const double* sqrt_ta
     MIC_ARG_CHECK(st && st->score && st->len && st->seq && sqrt_tab && tokens && lengths && score, "mic_beam_finalize: null pointer");
     MIC_ARG_CHECK(B > 0 && K >= 1 && K <= KMAX && t_cap > 0, "mic_beam_finalize: bad sizes");
     MIC_ARG_CHECK(!attn_out || (attn_hist && st->anc && S > 0), "mic_beam_finalize: attention output needs hist, anc and S");
-    hipLaunchKernelGGL(beam_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *st, sqrt_tab, B, K, t_cap, tokens, lengths, score,
+    MIC_LAUNCH(beam_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *st, sqrt_tab, B, K, t_cap, tokens, lengths, score,
                        attn_hist, S, attn_out);
-    MIC_LAUNCH_CHECK();
     return 0;
 }
 
@@ -367,8 +363,7 @@ extern "C" int mic_sample_update(const float* val, const int32_t* idx, int32_t* 
     MIC_ARG_CHECK(idx && tokens && finished && N > 0, "mic_sample_update: bad arguments");
     MIC_ARG_CHECK(!total || val, "mic_sample_update: total needs val");
     MIC_ARG_CHECK(pos >= 0 && pos < t_cap, "mic_sample_update: pos=%d outside t_cap=%d", pos, t_cap);
-    hipLaunchKernelGGL(sample_update_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, val, idx, tokens, t_cap, pos,
+    MIC_LAUNCH(sample_update_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, val, idx, tokens, t_cap, pos,
                        finished, total, live_rows, N, pad_id, eos_id);
-    MIC_LAUNCH_CHECK();
     return 0;
 }

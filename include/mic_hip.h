@@ -68,8 +68,17 @@ typedef struct mic_conv_desc {
     int32_t stride, pad_h, pad_w;
     int32_t ldc, ld_res;
     int32_t relu;
+    int32_t k_valid;      /* k entries that are not structural zero padding (0 = K); only used for FLOP accounting */
 } mic_conv_desc;
 int mic_conv2d(const mic_conv_desc* d, void* stream);
+
+/* Per-launch timing of the GEMM/conv kernel for roofline reports.  Between begin and end every
+ * mic_conv2d launch is bracketed by two hipEvents on its stream (no synchronisation).  end waits for
+ * the last event and returns, per tile variant v (0: 128x128, 1: 64x64) and dtype d (index 2*v+d),
+ * the number of launches, their summed duration in ms and their summed algorithmic FLOPs
+ * 2*M*N*k_valid.  No reference counterpart (the reference has no timing hooks); used by bench.py. */
+int mic_profile_begin(int max_launches);
+int mic_profile_end(int32_t count[4], double ms[4], double flops[4]);
 
 /* (B,3,H,W) fp32 planar image -> zero-bordered 4-channel pixel-major image
  * out[B][H+pad_t+pad_b][W+pad_l+pad_r][4] of `dtype` (channel 3 = 0).  Input staging for the
