@@ -13,6 +13,8 @@
 // before the MFMAs of tile k and written to the other LDS buffer after them; one barrier per tile.
 #include "mic_common.h"
 
+#include <stdlib.h>
+
 #include <mutex>
 #include <vector>
 
@@ -54,15 +56,21 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int KT>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     constexpr int VEC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
-    constexpr int EPR = 4 * VEC;              // K elements per tile row (64 bytes)
-    constexpr int XC = BM * 4 / 256, WC = BN * 4 / 256;
+    constexpr int EPR = 4 * VEC;              // K elements per 64-byte sub-tile row
+    constexpr int R4 = 4 * KT;                // 16-byte chunks per row per stage
+    constexpr int RSTEP = 256 / R4;           // rows covered by one pass of the 256 threads
+    constexpr int XC = BM / RSTEP, WC = BN / RSTEP;
     constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 MFMA tiles per wave along m / n
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * 64];
-    unsigned char* const sX = smem;
-    unsigned char* const sW = smem + 2 * BM * 64;
+    constexpr int STAGE = KT * (BM + BN) * 64;  // bytes of one stage: KT sub-tiles of X then of W
+    // epilogue staging: fp32 accumulators of PASS_ROWS rows, padded rows (conflict-light b128 writes)
+    constexpr int PASS_ROWS = BM == 128 ? 64 : BM;
+    constexpr int LDC_S = BN + 4;
+    constexpr int EPI = PASS_ROWS * LDC_S * 4;
+    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -79,57 +87,59 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const T* __restrict__ in = (const T*)a.in;
     const T* __restrict__ w = (const T*)a.w;
 
-    // per-thread gather coordinates of its activation chunks (fixed over the k loop)
+    // Each thread owns one (sub-tile, chunk) column of the stage and XC / WC rows of it, so
+    // R4 consecutive lanes read R4*16 contiguous bytes of one row.
+    const int within = tid % R4, kt_own = within >> 2, q_own = within & 3, row0 = tid / R4;
     long long x_img[XC];
-    int x_h[XC], x_w[XC], x_dst[XC];
+    int x_h[XC], x_w[XC];
     bool x_ok[XC];
 #pragma unroll
     for (int i = 0; i < XC; ++i) {
-        const int c = tid + i * 256, row = c >> 2, q = c & 3;
-        int m = m0 + row;
+        int m = m0 + row0 + i * RSTEP;
         x_ok[i] = m < a.M;
         m = x_ok[i] ? m : a.M - 1;
         const int b = m / a.OHW, r = m - b * a.OHW, oh = r / a.OW, ow = r - oh * a.OW;
-        x_img[i] = (long long)b * a.img_stride + q * VEC;
+        x_img[i] = (long long)b * a.img_stride + q_own * VEC;
         x_h[i] = oh * a.stride - a.pad_h;
         x_w[i] = ow * a.stride - a.pad_w;
-        x_dst[i] = lds_off(row, q);
     }
-    const T* w_src[WC];
-    int w_dst[WC];
-#pragma unroll
-    for (int i = 0; i < WC; ++i) {
-        const int c = tid + i * 256, row = c >> 2, q = c & 3;
-        w_src[i] = w + (long long)(n0 + row) * a.K + q * VEC;
-        w_dst[i] = lds_off(row, q);
-    }
+    const T* w_src = w + (long long)(n0 + row0) * a.K + kt_own * EPR + q_own * VEC;
+    const int x_dst = kt_own * BM * 64, w_dst = KT * BM * 64 + kt_own * BN * 64;
 
+    // tap position of this thread's k column (advances by one stage per load)
+    int k_cur = kt_own * EPR, kh, kw, c0;
+    {
+        const int tap = k_cur / a.run;
+        c0 = k_cur - tap * a.run;
+        kh = tap / a.kw_taps;
+        kw = tap - kh * a.kw_taps;
+    }
     uint4 xr[XC], wr[WC];
-    int kh = 0, kw = 0, c0 = 0;  // tap position of the tile being loaded (block-uniform)
-    auto load_tile = [&]() {
+    auto load_stage = [&]() {
+        const bool k_ok = k_cur < a.K;
 #pragma unroll
         for (int i = 0; i < XC; ++i) {
             const int ih = x_h[i] + kh, iw = x_w[i] + kw;
-            const bool ok = x_ok[i] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+            const bool ok = k_ok && x_ok[i] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
             const T* p = in + x_img[i] + (long long)ih * a.row_stride + (long long)iw * a.pix_stride + c0;
             xr[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < WC; ++i) {
-            wr[i] = *reinterpret_cast<const uint4*>(w_src[i]);
-            w_src[i] += EPR;
-        }
-        c0 += EPR;
-        if (c0 == a.run) {
-            c0 = 0;
+        for (int i = 0; i < WC; ++i)
+            wr[i] = k_ok ? *reinterpret_cast<const uint4*>(w_src + (long long)i * RSTEP * a.K) : make_uint4(0, 0, 0, 0);
+        w_src += KT * EPR;
+        k_cur += KT * EPR;
+        c0 += KT * EPR;
+        while (c0 >= a.run) {
+            c0 -= a.run;
             if (++kw == a.kw_taps) { kw = 0; ++kh; }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < XC; ++i) *reinterpret_cast<uint4*>(sX + buf * BM * 64 + x_dst[i]) = xr[i];
+        for (int i = 0; i < XC; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + x_dst + lds_off(row0 + i * RSTEP, q_own)) = xr[i];
 #pragma unroll
-        for (int i = 0; i < WC; ++i) *reinterpret_cast<uint4*>(sW + buf * BN * 64 + w_dst[i]) = wr[i];
+        for (int i = 0; i < WC; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_dst + lds_off(row0 + i * RSTEP, q_own)) = wr[i];
     };
 
     f32x4_t acc[TN][TM];
@@ -142,102 +152,133 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) xf_off[i] = lds_off(wm * (BM / 2) + i * 16 + (lane & 15), lane >> 4);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) wf_off[j] = lds_off(wn * (BN / 2) + j * 16 + (lane & 15), lane >> 4);
+    for (int j = 0; j < TN; ++j) wf_off[j] = KT * BM * 64 + lds_off(wn * (BN / 2) + j * 16 + (lane & 15), lane >> 4);
 
-    load_tile();
-    store_tile(0);
+    load_stage();
+    store_stage(0);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < a.nk; ++kt) {
-        const bool more = kt + 1 < a.nk;
-        if (more) load_tile();
-        uint4 xf[TM], wf[TN];
+    for (int st = 0; st < a.nk; ++st) {
+        const bool more = st + 1 < a.nk;
+        if (more) load_stage();
+        const unsigned char* base = smem + cur * STAGE;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const uint4*>(sX + cur * BM * 64 + xf_off[i]);
+        for (int kt = 0; kt < KT; ++kt) {
+            uint4 xf[TM], wf[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(sW + cur * BN * 64 + wf_off[j]);
+            for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const uint4*>(base + kt * BM * 64 + xf_off[i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(base + kt * BN * 64 + wf_off[j]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
-        if (more) store_tile(cur ^ 1);
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+        }
+        if (more) store_stage(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // epilogue: lane holds channels n..n+3 of pixel m for each (j, i) tile
+    // Epilogue through LDS: each lane holds channels n..n+3 of pixel m per 16x16 tile; staging the
+    // fp32 tile lets every thread then handle 8 consecutive channels of one pixel, so bias /
+    // residual reads and the output store are full-row coalesced 16-byte accesses.
+    float* sC = reinterpret_cast<float*>(smem);
+    constexpr int NPASS = BM / PASS_ROWS;
+    constexpr int CPR = BN / 8;                    // 8-channel chunks per row
+    constexpr int CHUNKS = PASS_ROWS * CPR / 256;  // per thread per pass
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-        if (n >= a.N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (NPASS == 1 || wm == pass) {
+            const int rbase = NPASS == 1 ? wm * (BM / 2) : 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < a.N) bv[e] = a.bias[n + e];
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = rbase + i * 16 + (lane & 15), cidx = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                    *reinterpret_cast<f32x4_t*>(sC + r * LDC_S + cidx) = acc[j][i];
+                }
         }
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-            if (m >= a.M) continue;
-            float v[4];
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int c = tid + i * 256, r = c / CPR, ch = c - r * CPR;
+            const int m = m0 + pass * PASS_ROWS + r, n = n0 + ch * 8;
+            if (m >= a.M || n >= a.N) continue;
+            float v[8];
+            {
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(sC + r * LDC_S + ch * 8);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(sC + r * LDC_S + ch * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bv[e];
-            const bool full = a.vec_ok && n + 3 < a.N;
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+            }
+            const bool full = a.vec_ok && n + 7 < a.N;
+            if (a.bias) {
+                if (full) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n), b1 = *reinterpret_cast<const float4*>(a.bias + n + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < a.N) v[e] += a.bias[n + e];
+                }
+            }
             if (a.res) {
                 const long long ro = (long long)m * a.ld_res + n;
                 if (a.res_dtype == MIC_F32) {
-                    const float* r = (const float*)a.res + ro;
+                    const float* rp = (const float*)a.res + ro;
                     if (full) {
-                        const float4 t = *reinterpret_cast<const float4*>(r);
-                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < a.N) v[e] += r[e];
+                        for (int e = 0; e < 8; ++e)
+                            if (n + e < a.N) v[e] += rp[e];
                     }
                 } else {
-                    const bf16_t* r = (const bf16_t*)a.res + ro;
+                    const bf16_t* rp = (const bf16_t*)a.res + ro;
                     if (full) {
-                        struct alignas(8) B4 { bf16_t v[4]; };
-                        const B4 t = *reinterpret_cast<const B4*>(r);
+                        const Vec16<bf16_t> t = ld16(rp);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)t.v[e];
+                        for (int e = 0; e < 8; ++e) v[e] += (float)t.v[e];
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < a.N) v[e] += (float)r[e];
+                        for (int e = 0; e < 8; ++e)
+                            if (n + e < a.N) v[e] += (float)rp[e];
                     }
                 }
             }
             if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             const long long oo = (long long)m * a.ldc + n;
             if (a.out_dtype == MIC_F32) {
                 float* o = (float*)a.out + oo;
                 if (full) {
                     *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 8; ++e)
                         if (n + e < a.N) o[e] = v[e];
                 }
             } else {
                 bf16_t* o = (bf16_t*)a.out + oo;
                 if (full) {
-                    struct alignas(8) B4 { bf16_t v[4]; } p;
+                    Vec16<bf16_t> p;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) p.v[e] = (bf16_t)v[e];
-                    *reinterpret_cast<B4*>(o) = p;
+                    for (int e = 0; e < 8; ++e) p.v[e] = (bf16_t)v[e];
+                    st16(o, p);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 8; ++e)
                         if (n + e < a.N) o[e] = (bf16_t)v[e];
                 }
             }
         }
+        if (pass + 1 < NPASS) __syncthreads();
     }
 }
 
@@ -252,29 +293,60 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 bool g_prof_on = false;
 
-template <typename T, int BM, int BN> int launch(IgemmArgs& a, hipStream_t s, double flops) {
+template <typename T, int BM, int BN, int KT> int launch(IgemmArgs& a, hipStream_t s, double flops) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     const int grid = a.tiles_m * a.tiles_n;
+    constexpr int kstage = KT * 64 / (int)sizeof(T);
+    a.nk = (a.K + kstage - 1) / kstage;
     ProfRec* rec = nullptr;
     if (g_prof_on) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof_on && g_prof_used < g_prof.size()) {
             rec = &g_prof[g_prof_used++];
-            rec->slot = (BM == 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0);
+            rec->slot = (BM == 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0);  // all 128-row tiles share a slot
             rec->flops = flops;
         }
     }
     if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e0, s));
-    MIC_LAUNCH((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), 0, s, a);
+    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT>), dim3(grid), dim3(256), 0, s, a);
     if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e1, s));
     return 0;
 }
 
+// Tile variants: (BM, BN, KT).  The heuristic below picks one from the problem shape; the
+// environment variable MIC_IGEMM_FORCE=<index> pins one for tuning runs.
 template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
-    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (t128 >= 192) return launch<T, 128, 128>(a, s, flops);
-    return launch<T, 64, 64>(a, s, flops);
+    static const int forced = [] {
+        const char* e = getenv("MIC_IGEMM_FORCE");
+        return e ? atoi(e) : -1;
+    }();
+    int v = forced;
+    if (v < 0) {
+        // measured on MI355X over the ResNet-50 (batch 256) and decode-step shapes: shallow stages win
+        // through occupancy unless K is long; N <= 64 wastes half of a 128-wide tile; problems with
+        // few tiles take 64x64 tiles, deeper stages when there are fewer of them than CUs
+        const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        if (t128 >= 192) {
+            if (a.N <= 64) v = 8;
+            else v = a.K >= 2048 ? 1 : 0;
+        } else {
+            const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+            v = t64 > 256 ? 4 : 5;
+        }
+    }
+    switch (v) {
+        case 0: return launch<T, 128, 128, 1>(a, s, flops);
+        case 1: return launch<T, 128, 128, 2>(a, s, flops);
+        case 2: return launch<T, 128, 128, 4>(a, s, flops);
+        case 3: return launch<T, 128, 64, 2>(a, s, flops);
+        case 4: return launch<T, 64, 64, 2>(a, s, flops);
+        case 5: return launch<T, 64, 64, 4>(a, s, flops);
+        case 6: return launch<T, 64, 64, 8>(a, s, flops);
+        case 7: return launch<T, 128, 64, 4>(a, s, flops);
+        case 8: return launch<T, 128, 64, 1>(a, s, flops);
+        default: mic_set_error("mic_conv2d: unknown tile variant %d", v); return MIC_ERR_ARG;
+    }
 }
 
 }  // namespace
@@ -306,10 +378,9 @@ extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
     a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
     a.ldc = d->ldc; a.ld_res = d->ld_res; a.relu = d->relu;
     a.out_dtype = d->out_dtype; a.res_dtype = d->res_dtype;
-    a.nk = d->K / epr;
-    const size_t osz = mic_dtype_size(d->out_dtype);
-    a.vec_ok = (d->ldc % 4 == 0) && (((uintptr_t)d->out) % (4 * osz) == 0) &&
-               (!d->res || (d->ld_res % 4 == 0 && ((uintptr_t)d->res) % 16 == 0));
+    // 8 consecutive channels per thread: 16-byte bf16 / 2x16-byte fp32 accesses need these alignments
+    a.vec_ok = (d->ldc % 8 == 0) && (((uintptr_t)d->out) % 16 == 0) && (!d->bias || ((uintptr_t)d->bias) % 16 == 0) &&
+               (!d->res || (d->ld_res % 8 == 0 && ((uintptr_t)d->res) % 16 == 0));
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * d->N * (d->k_valid > 0 ? d->k_valid : d->K);
     return d->dtype == MIC_BF16 ? dispatch<bf16_t>(a, s, flops) : dispatch<float>(a, s, flops);

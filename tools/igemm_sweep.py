@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Times mic_conv2d on every convolution shape of the ResNet-50 encoder (batch 256, 224x224) and
+on the decode-step GEMM shapes, one by one, with HIP events.  Development aid for tile tuning."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import image_captioning_amd as amd  # noqa: E402
+
+L = amd._lib
+DEV = "cuda:0"
+
+
+def layers(B=256):
+    out = [("stem", B, 230, 232, 4, 64, 7, 1, 2, 0, 32, 147)]  # name,B,IH,IW,Cpix,Cout,kh,kw,stride,pad,run,k_valid
+    cin, h = 64, 56
+    for si, (w, nb, st) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]):
+        for b in range(nb):
+            s = st if b == 0 else 1
+            out.append((f"s{si}b{b}c1", B, h, h, cin, w, 1, 1, 1, 0, cin, 0))
+            out.append((f"s{si}b{b}c2", B, h, h, w, w, 3, 3, s, 1, w, 0))
+            if b == 0:
+                out.append((f"s{si}b{b}ds", B, h, h, cin, 4 * w, 1, 1, s, 0, cin, 0))
+            out.append((f"s{si}b{b}c3+res", B, h // s, h // s, w, 4 * w, 1, 1, 1, 0, w, 0))
+            cin, h = 4 * w, h // s
+    out.append(("proj", B, 7, 7, 2048, 512, 1, 1, 1, 0, 2048, 0))
+    return out
+
+
+def run(desc, iters=10):
+    for _ in range(2):
+        L.check(L.lib.mic_conv2d(C.byref(desc), L.stream_ptr()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        L.check(L.lib.mic_conv2d(C.byref(desc), L.stream_ptr()))
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    dt = torch.bfloat16
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    tot = 0.0
+    seen = {}
+    for (name, B, IH, IW, cpix, cout, kh, kw, stride, pad, run_, kv) in layers():
+        key = (IH, IW, cpix, cout, kh, stride, "res" in name)
+        if only and only not in name:
+            continue
+        stem = name == "stem"
+        OH = (IH - 7) // 2 + 1 if stem else (IH + 2 * pad - kh) // stride + 1
+        OW = 112 if stem else (IW + 2 * pad - kw) // stride + 1
+        K = kh * kw * run_
+        M = B * OH * OW
+        if key in seen:
+            us = seen[key]
+        else:
+            x = torch.randn(B, IH, IW, cpix, device=DEV).to(dt)
+            w = (torch.randn((cout + 127) // 128 * 128, K, device=DEV) * 0.05).to(dt)
+            bias = torch.randn(cout, device=DEV)
+            res = torch.randn(M, cout, device=DEV).to(dt) if "res" in name else None
+            out = torch.empty(M, cout, device=DEV, dtype=dt)
+            d = L.ConvDesc()
+            d.in_, d.w, d.bias, d.res, d.out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), L.ptr(res), out.data_ptr()
+            d.dtype = d.out_dtype = d.res_dtype = L.BF16
+            d.M, d.N, d.K, d.OH, d.OW, d.IH, d.IW = M, cout, K, OH, OW, IH, IW
+            d.in_img_stride, d.in_row_stride, d.in_pix_stride = IH * IW * cpix, IW * cpix, cpix
+            d.kw_taps, d.run, d.stride, d.pad_h, d.pad_w = kw, run_, stride, pad, pad
+            d.ldc, d.ld_res, d.relu = cout, cout, 1
+            us = run(d)
+            seen[key] = us
+            del x, w, res, out
+        fl = 2.0 * M * cout * (kv or K)
+        by = 2.0 * (M * (kv or K) / (kh * kw if not stem else 1) * (1 if stride == 1 else 1) + M * cout * (2 if "res" in name else 1))
+        tot += us
+        print(f"{name:12s} M={M:8d} N={cout:5d} K={K:5d} {us:8.1f} us {fl / us / 1e6:7.1f} TF  ~{by / us / 1e6:5.2f} TB/s")
+    print(f"encoder GEMM total {tot / 1e3:.2f} ms")
+    if only:
+        return
+    for (M, N, K, nm) in [(768, 1536, 512, "qkv"), (768, 512, 512, "proj"), (768, 1024, 512, "ff1"), (768, 512, 1024, "ff2"),
+                          (768, 3500, 512, "vocab"), (12544, 1024, 512, "cross_kv")]:
+        x = torch.randn(M, K, device=DEV).to(dt)
+        w = (torch.randn((N + 127) // 128 * 128, K, device=DEV) * 0.05).to(dt)
+        out = torch.empty(M, N, device=DEV)
+        d = L.ConvDesc()
+        d.in_, d.w, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+        d.dtype, d.out_dtype = L.BF16, L.F32
+        d.M, d.N, d.K, d.OH, d.OW, d.IH, d.IW = M, N, K, 1, 1, 1, 1
+        d.in_img_stride, d.in_pix_stride, d.kw_taps, d.run, d.stride, d.ldc = K, 4, 1, K, 1, N
+        us = run(d, 50)
+        print(f"{nm:12s} M={M:8d} N={N:5d} K={K:5d} {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF")
+
+
+if __name__ == "__main__":
+    main()
