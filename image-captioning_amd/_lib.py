@@ -47,7 +47,7 @@ _TR_LN = ["ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b"]
 
 
 class TrLayer(C.Structure):
-    _fields_ = [(n, vp) for n in _TR_W + _TR_B + _TR_LN]
+    _fields_ = [(n, vp) for n in _TR_W + _TR_B + _TR_LN + ["self_out_wf", "cross_out_wf", "ff2_wf"]]
 
 
 class TrDecoder(C.Structure):
@@ -86,6 +86,9 @@ SIGNATURES = {
     "mic_global_avgpool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_embed_pos": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_pack_weight_frag": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_linear_res_ln_supported": (C.c_int, [C.c_int]),
+    "mic_linear_res_ln": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_self_attn_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_cross_attn_step": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, f32, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -102,9 +105,9 @@ SIGNATURES = {
     "mic_tr_cross_kv": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, vp]),
     "mic_tr_step": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mic_tr_beam_steps": (C.c_int, [P(TrDecoder), P(TrWorkspace), P(BeamState), vp, vp, vp, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_int, C.c_int, vp]),
+                                    C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_tr_sample_steps": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.c_int, vp]),
+                                      C.c_int, C.c_int, C.c_int, vp]),
     "mic_lstm_step": (C.c_int, [P(LstmDecoder), P(LstmWorkspace), vp, C.c_int, C.c_int, vp, C.c_int, vp]),
 }
 

@@ -2,7 +2,70 @@
 // steps) on one stream so the host makes one call per phase instead of one per kernel.
 #include "mic_common.h"
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace {
+
+// ---- HIP-graph cache for the launch-bound decode loops ---------------------------------------
+// A run of decode steps is ~40 dependent small kernels per step whose arguments depend only on the
+// driver's arguments, so the whole run is captured once per distinct argument set and replayed.
+struct GraphCache {
+    std::mutex mu;
+    std::map<std::string, hipGraphExec_t> map;
+    std::vector<std::string> order;
+};
+GraphCache g_graphs;
+
+// body(stream) enqueues the work.  Capture runs on a stream the library owns (the caller's may be
+// the legacy default stream, which cannot be captured); the executable is launched on the caller's.
+template <class Body> int run_graphed(const std::string& key, hipStream_t s, Body&& body) {
+    std::lock_guard<std::mutex> lk(g_graphs.mu);
+    auto it = g_graphs.map.find(key);
+    if (it == g_graphs.map.end()) {
+        hipGraph_t graph = nullptr;
+        hipStream_t cap = nullptr;
+        MIC_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(cap);
+            MIC_HIP_CHECK(e);
+        }
+        const int rc = body(cap);
+        e = hipStreamEndCapture(cap, &graph);
+        (void)hipStreamDestroy(cap);
+        if (rc != 0) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        MIC_HIP_CHECK(e);
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        MIC_HIP_CHECK(ei);
+        if (g_graphs.order.size() >= 32) {  // bounded: drop the oldest executable
+            auto old = g_graphs.map.find(g_graphs.order.front());
+            if (old != g_graphs.map.end()) {
+                (void)hipGraphExecDestroy(old->second);
+                g_graphs.map.erase(old);
+            }
+            g_graphs.order.erase(g_graphs.order.begin());
+        }
+        it = g_graphs.map.emplace(key, exec).first;
+        g_graphs.order.push_back(key);
+    }
+    MIC_HIP_CHECK(hipGraphLaunch(it->second, s));
+    return 0;
+}
+
+template <class... Ts> std::string make_key(const char* tag, const Ts&... parts) {
+    std::string k(tag);
+    auto add = [&k](const void* p, size_t n) { k.append(reinterpret_cast<const char*>(p), n); };
+    (add(&parts, sizeof(parts)), ...);
+    return k;
+}
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
@@ -125,6 +188,15 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
 // transformer decoder
 // ---------------------------------------------------------------------------------------------
 namespace {
+// x <- LayerNorm(in W^T + b + x): one fused launch when the hidden size has a fused variant,
+// otherwise GEMM (+bias +residual) into y followed by the LayerNorm kernel
+int res_ln(int dt, const void* wf, const void* in, int ld_in, int K, const void* w, const float* b, const float* g, const float* be,
+           const mic_tr_workspace* ws, int N, int H, hipStream_t s) {
+    if (wf) return mic_linear_res_ln(in, ld_in, wf, b, ws->x, H, g, be, ws->x, ws->xt, H, dt, N, K, H, s);
+    MIC_TRY(linear(dt, in, ld_in, N, K, w, b, ws->x, MIC_F32, H, ws->y, MIC_F32, H, H, 0, s));
+    return mic_layernorm(ws->y, g, be, ws->x, ws->xt, H, dt, N, H, s);
+}
+
 int check_tr(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
     MIC_ARG_CHECK(dec && ws, "transformer driver: null pointer");
     MIC_ARG_CHECK(dec->dtype == MIC_F32 || dec->dtype == MIC_BF16, "transformer driver: bad dtype");
@@ -161,14 +233,14 @@ extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws
     MIC_ARG_CHECK(attn_mode == 0 || ws->attn, "mic_tr_step: attention requested without a buffer");
     hipStream_t s = (hipStream_t)stream;
     const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
+    const bool fused = mic_linear_res_ln_supported(H) != 0;
     MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
     for (int l = 0; l < L; ++l) {
         const mic_tr_layer& Y = dec->layer[l];
         // masked self-attention over the cache + residual + LayerNorm
         MIC_TRY(linear(dt, ws->xt, H, N, H, Y.self_in_w, Y.self_in_b, nullptr, 0, 0, ws->qkv, MIC_F32, 3 * H, 3 * H, 0, s));
         MIC_TRY(mic_self_attn_step(ws->qkv, ws->kcache[l], ws->vcache[l], anc, t, ws->t_cap, ws->o, H, dt, N, H, dec->heads, s));
-        MIC_TRY(linear(dt, ws->o, H, N, H, Y.self_out_w, Y.self_out_b, ws->x, MIC_F32, H, ws->y, MIC_F32, H, H, 0, s));
-        MIC_TRY(mic_layernorm(ws->y, Y.ln1_g, Y.ln1_b, ws->x, ws->xt, H, dt, N, H, s));
+        MIC_TRY(res_ln(dt, fused ? Y.self_out_wf : nullptr, ws->o, H, H, Y.self_out_w, Y.self_out_b, Y.ln1_g, Y.ln1_b, ws, N, H, s));
         // cross-attention against the image's cached K/V + residual + LayerNorm
         MIC_TRY(linear(dt, ws->xt, H, N, H, Y.cross_q_w, Y.cross_q_b, nullptr, 0, 0, ws->qkv, MIC_F32, H, H, 0, s));
         float* ap = nullptr;
@@ -181,52 +253,58 @@ extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws
         }
         MIC_TRY(mic_cross_attn_step(ws->qkv, H, ws->cross_kv[l], S, ws->rows_per_image, ws->o, H, ap, ld_attn, scale, accumulate, dt,
                                     N, H, dec->heads, s));
-        MIC_TRY(linear(dt, ws->o, H, N, H, Y.cross_out_w, Y.cross_out_b, ws->x, MIC_F32, H, ws->y, MIC_F32, H, H, 0, s));
-        MIC_TRY(mic_layernorm(ws->y, Y.ln2_g, Y.ln2_b, ws->x, ws->xt, H, dt, N, H, s));
+        MIC_TRY(res_ln(dt, fused ? Y.cross_out_wf : nullptr, ws->o, H, H, Y.cross_out_w, Y.cross_out_b, Y.ln2_g, Y.ln2_b, ws, N, H, s));
         // feed-forward + residual + LayerNorm
         MIC_TRY(linear(dt, ws->xt, H, N, H, Y.ff1_w, Y.ff1_b, nullptr, 0, 0, ws->ffh, dt, 2 * H, 2 * H, 1, s));
-        MIC_TRY(linear(dt, ws->ffh, 2 * H, N, 2 * H, Y.ff2_w, Y.ff2_b, ws->x, MIC_F32, H, ws->y, MIC_F32, H, H, 0, s));
-        MIC_TRY(mic_layernorm(ws->y, Y.ln3_g, Y.ln3_b, ws->x, ws->xt, H, dt, N, H, s));
+        MIC_TRY(res_ln(dt, fused ? Y.ff2_wf : nullptr, ws->ffh, 2 * H, 2 * H, Y.ff2_w, Y.ff2_b, Y.ln3_g, Y.ln3_b, ws, N, H, s));
     }
     return linear(dt, ws->xt, H, N, H, dec->out_w, dec->out_b, nullptr, 0, 0, ws->logits, MIC_F32, dec->vocab, dec->vocab, 0, s);
 }
 
 extern "C" int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const mic_beam_state st[2], int32_t* parent,
                                  int32_t* live_images, const double* sqrt_tab, int B, int K, int t0, int t1, int eos_id,
-                                 int want_attn, void* stream) {
+                                 int want_attn, int use_graph, void* stream) {
     MIC_TRY(check_tr(dec, ws));
     MIC_ARG_CHECK(st && parent && live_images && sqrt_tab && ws->top_val && ws->top_idx, "mic_tr_beam_steps: null pointer");
     MIC_ARG_CHECK(B * K == ws->N && ws->rows_per_image == K, "mic_tr_beam_steps: workspace rows %d != B*K = %d*%d", ws->N, B, K);
     MIC_ARG_CHECK(t0 >= 0 && t1 >= t0 && t1 + 1 <= ws->t_cap, "mic_tr_beam_steps: steps [%d,%d) do not fit t_cap=%d", t0, t1, ws->t_cap);
-    for (int t = t0; t < t1; ++t) {
-        const mic_beam_state* cur = &st[t & 1];
-        const mic_beam_state* nxt = &st[(t + 1) & 1];
-        MIC_TRY(mic_tr_step(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, stream));
-        MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, ws->N, dec->vocab, K, 1.0f, 0, ws->top_val, ws->top_idx, nullptr, stream));
-        MIC_TRY(mic_beam_select(cur, nxt, ws->top_val, ws->top_idx, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t,
-                                ws->t_cap, eos_id, 0, stream));
-    }
-    return 0;
+    auto body = [&](void* stream) -> int {
+        for (int t = t0; t < t1; ++t) {
+            const mic_beam_state* cur = &st[t & 1];
+            const mic_beam_state* nxt = &st[(t + 1) & 1];
+            MIC_TRY(mic_tr_step(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, stream));
+            MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, ws->N, dec->vocab, K, 1.0f, 0, ws->top_val, ws->top_idx, nullptr, stream));
+            MIC_TRY(mic_beam_select(cur, nxt, ws->top_val, ws->top_idx, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t,
+                                    ws->t_cap, eos_id, 0, stream));
+        }
+        return 0;
+    };
+    if (!use_graph || t1 == t0) return body(stream);
+    return run_graphed(make_key("beam", *dec, *ws, st[0], st[1], parent, live_images, sqrt_tab, B, K, t0, t1, eos_id, want_attn), (hipStream_t)stream, body);
 }
 
 extern "C" int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, int32_t* tokens, uint8_t* finished,
                                    float* total, int32_t* live_rows, float inv_temp, const float* u, int t0, int t1, int pad_id,
-                                   int eos_id, int want_attn, void* stream) {
+                                   int eos_id, int want_attn, int use_graph, void* stream) {
     MIC_TRY(check_tr(dec, ws));
     MIC_ARG_CHECK(tokens && finished && total && live_rows && ws->top_val && ws->top_idx, "mic_tr_sample_steps: null pointer");
     MIC_ARG_CHECK(ws->rows_per_image == 1, "mic_tr_sample_steps: one row per image expected");
     MIC_ARG_CHECK(t0 >= 0 && t1 >= t0 && t1 + 1 <= ws->t_cap, "mic_tr_sample_steps: steps [%d,%d) do not fit t_cap=%d", t0, t1, ws->t_cap);
-    for (int t = t0; t < t1; ++t) {
-        MIC_TRY(mic_tr_step(dec, ws, tokens, ws->t_cap, nullptr, t, want_attn ? 2 : 0, stream));
-        if (u)
-            MIC_TRY(mic_sample_multinomial(ws->logits, dec->vocab, ws->N, dec->vocab, inv_temp, u + (int64_t)t * ws->N, ws->top_val,
-                                           ws->top_idx, stream));
-        else
-            MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, ws->N, dec->vocab, 1, 1.0f, 0, ws->top_val, ws->top_idx, nullptr, stream));
-        MIC_TRY(mic_sample_update(ws->top_val, ws->top_idx, tokens, ws->t_cap, t + 1, finished, total, live_rows + t, ws->N, pad_id,
-                                  eos_id, stream));
-    }
-    return 0;
+    auto body = [&](void* stream) -> int {
+        for (int t = t0; t < t1; ++t) {
+            MIC_TRY(mic_tr_step(dec, ws, tokens, ws->t_cap, nullptr, t, want_attn ? 2 : 0, stream));
+            if (u)
+                MIC_TRY(mic_sample_multinomial(ws->logits, dec->vocab, ws->N, dec->vocab, inv_temp, u + (int64_t)t * ws->N, ws->top_val,
+                                               ws->top_idx, stream));
+            else
+                MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, ws->N, dec->vocab, 1, 1.0f, 0, ws->top_val, ws->top_idx, nullptr, stream));
+            MIC_TRY(mic_sample_update(ws->top_val, ws->top_idx, tokens, ws->t_cap, t + 1, finished, total, live_rows + t, ws->N, pad_id,
+                                      eos_id, stream));
+        }
+        return 0;
+    };
+    if (!use_graph || t1 == t0) return body(stream);
+    return run_graphed(make_key("samp", *dec, *ws, tokens, finished, total, live_rows, inv_temp, u, t0, t1, pad_id, eos_id, want_attn), (hipStream_t)stream, body);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -300,7 +300,9 @@ template <typename T, int BM, int BN, int KT> int launch(IgemmArgs& a, hipStream
     constexpr int kstage = KT * 64 / (int)sizeof(T);
     a.nk = (a.K + kstage - 1) / kstage;
     ProfRec* rec = nullptr;
-    if (g_prof_on) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (g_prof_on) (void)hipStreamIsCapturing(s, &cap);
+    if (g_prof_on && cap == hipStreamCaptureStatusNone) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof_on && g_prof_used < g_prof.size()) {
             rec = &g_prof[g_prof_used++];

@@ -22,7 +22,7 @@ from .vocabulary import EOS, PAD, SOS
 
 class ImageCaptioner:
     def __init__(self, vocab, num_heads: int = 2, dtype: torch.dtype = torch.bfloat16, encoder: str = "resnet50",
-                 sync_every: int = 8):
+                 sync_every: int = 8, use_graph: bool = True):
         if encoder not in ("resnet50", "none"):
             raise ValueError(f"Encoder {encoder} not recognized")
         self.vocab = vocab
@@ -30,6 +30,7 @@ class ImageCaptioner:
         self.dtype = dtype
         self.encoder_kind = encoder
         self.sync_every = max(1, int(sync_every))
+        self.use_graph = bool(use_graph)  # replay each run of decode steps as one HIP graph
         self._sd = None
         self.device = None
         self.encoder = None
@@ -119,18 +120,23 @@ class ImageCaptioner:
         K, dev = beam_size, self.device
         N, t_cap = B * K, max_len + 1
         ws, t = self._workspace(N, t_cap, S, K, K, 1 if return_attn else 0)
-        st_t, st = [], (L.BeamState * 2)()
-        for i in range(2):
-            score = torch.zeros(N, dtype=torch.float64, device=dev)
-            ln = torch.ones(N, dtype=torch.int32, device=dev)
-            seq = torch.full((N, t_cap), self.vocab.str_to_idx(SOS), dtype=torch.int32, device=dev)
-            anc = torch.zeros(N, t_cap, dtype=torch.int32, device=dev)
-            st_t.append((score, ln, seq, anc))
-            st[i].score, st[i].len, st[i].seq, st[i].anc = score.data_ptr(), ln.data_ptr(), seq.data_ptr(), anc.data_ptr()
-        parent = torch.empty(N, dtype=torch.int32, device=dev)
-        live = torch.zeros(max(t_cap, 1), dtype=torch.int32, device=dev)
-        # len ** 0.5 exactly as the reference's Python evaluates it (models/transformer.py:627)
-        sqrt_tab = torch.tensor([float(i) ** 0.5 for i in range(t_cap + 2)], dtype=torch.float64).to(dev)
+        sos = self.vocab.str_to_idx(SOS)
+        if "beam" not in t:  # search state lives with the workspace so that repeated calls reuse addresses
+            st = (L.BeamState * 2)()
+            bufs = []
+            for i in range(2):
+                b = (torch.empty(N, dtype=torch.float64, device=dev), torch.empty(N, dtype=torch.int32, device=dev),
+                     torch.empty(N, t_cap, dtype=torch.int32, device=dev), torch.empty(N, t_cap, dtype=torch.int32, device=dev))
+                bufs.append(b)
+                st[i].score, st[i].len, st[i].seq, st[i].anc = (x.data_ptr() for x in b)
+            # len ** 0.5 exactly as the reference's Python evaluates it (models/transformer.py:627)
+            sqrt_tab = torch.tensor([float(i) ** 0.5 for i in range(t_cap + 2)], dtype=torch.float64).to(dev)
+            t["beam"] = (st, bufs, torch.empty(N, dtype=torch.int32, device=dev), torch.empty(max(t_cap, 1), dtype=torch.int32, device=dev),
+                         sqrt_tab)
+        st, bufs, parent, live, sqrt_tab = t["beam"]
+        for score_, len_, seq_, anc_ in bufs:
+            score_.zero_(); len_.fill_(1); seq_.fill_(sos); anc_.zero_()
+        live.zero_()
         stream = L.stream_ptr()
         L.check(L.lib.mic_tr_cross_kv(C.byref(self.dec), C.byref(ws), feats.data_ptr(), stream), "mic_tr_cross_kv")
         eos = self.vocab.str_to_idx(EOS)
@@ -138,7 +144,8 @@ class ImageCaptioner:
         while t0 < max_len:
             t1 = min(max_len, t0 + self.sync_every)
             L.check(L.lib.mic_tr_beam_steps(C.byref(self.dec), C.byref(ws), st, parent.data_ptr(), live.data_ptr(),
-                                            sqrt_tab.data_ptr(), B, K, t0, t1, eos, int(return_attn), stream), "mic_tr_beam_steps")
+                                            sqrt_tab.data_ptr(), B, K, t0, t1, eos, int(return_attn), int(self.use_graph), stream),
+                    "mic_tr_beam_steps")
             t0 = t1
             if t0 < max_len and int(live[t0 - 1].item()) == 0:  # every image's beams have ended
                 break
@@ -149,7 +156,6 @@ class ImageCaptioner:
         L.check(L.lib.mic_beam_finalize(C.byref(st[t0 & 1]), sqrt_tab.data_ptr(), B, K, t_cap, tokens.data_ptr(), lengths.data_ptr(),
                                         score.data_ptr(), t["attn"].data_ptr() if return_attn else None, S,
                                         L.ptr(attn), stream), "mic_beam_finalize")
-        self._keep_alive = (st_t, parent, live, sqrt_tab)
         return tokens, lengths, score, attn
 
     def sample_ids(self, feats: torch.Tensor, max_len: int, temp: Optional[float], return_attn: bool = False,
@@ -162,18 +168,24 @@ class ImageCaptioner:
         hot = temp is not None and temp > 0
         t_cap = max(max_len, 1)
         ws, t = self._workspace(B, t_cap, S, 1, 1, 2 if return_attn else 0)
-        tokens = torch.full((B, t_cap), self.vocab.str_to_idx(PAD), dtype=torch.int32, device=dev)
+        if "samp" not in t:
+            t["samp"] = (torch.empty(B, t_cap, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.uint8, device=dev),
+                         torch.empty(B, dtype=torch.float32, device=dev), torch.empty(t_cap, dtype=torch.int32, device=dev),
+                         torch.empty(max(t_cap - 1, 1), B, dtype=torch.float32, device=dev))
+        tokens, finished, total, live, ubuf = t["samp"]
+        tokens.fill_(self.vocab.str_to_idx(PAD))
         tokens[:, 0] = self.vocab.str_to_idx(SOS)
-        finished = torch.zeros(B, dtype=torch.uint8, device=dev)
-        total = torch.zeros(B, dtype=torch.float32, device=dev)
-        live = torch.zeros(t_cap, dtype=torch.int32, device=dev)
+        finished.zero_(); total.zero_(); live.zero_()
         steps = max_len - 1
         u = None
-        if hot:
-            u = uniforms if uniforms is not None else torch.rand(max(steps, 1), B, device=dev)
-            u = u.to(dev, torch.float32).contiguous()
-            if u.shape[0] < steps or u.shape[1] != B:
-                raise ValueError(f"uniforms must have shape (>={steps}, {B})")
+        if hot and steps > 0:
+            if uniforms is None:
+                ubuf.uniform_()
+            else:
+                if uniforms.shape[0] < steps or uniforms.shape[1] != B:
+                    raise ValueError(f"uniforms must have shape (>={steps}, {B})")
+                ubuf[:steps].copy_(uniforms[:steps].to(dev, torch.float32))
+            u = ubuf
         stream = L.stream_ptr()
         L.check(L.lib.mic_tr_cross_kv(C.byref(self.dec), C.byref(ws), feats.data_ptr(), stream), "mic_tr_cross_kv")
         t0, done_steps = 0, steps
@@ -181,7 +193,8 @@ class ImageCaptioner:
             t1 = min(steps, t0 + self.sync_every)
             L.check(L.lib.mic_tr_sample_steps(C.byref(self.dec), C.byref(ws), tokens.data_ptr(), finished.data_ptr(), total.data_ptr(),
                                               live.data_ptr(), (1.0 / temp) if hot else 1.0, L.ptr(u), t0, t1,
-                                              self.vocab.str_to_idx(PAD), self.vocab.str_to_idx(EOS), int(return_attn), stream),
+                                              self.vocab.str_to_idx(PAD), self.vocab.str_to_idx(EOS), int(return_attn),
+                                              int(self.use_graph), stream),
                     "mic_tr_sample_steps")
             lv = live[t0:t1].tolist()
             t0 = t1
@@ -189,7 +202,7 @@ class ImageCaptioner:
                 done_steps = t1 - len(lv) + lv.index(0) + 1
                 break
         attn = t["attn"][:, :done_steps].clone() if return_attn else None
-        return tokens[:, : done_steps + 1], total, attn
+        return tokens[:, : done_steps + 1].clone(), total.clone(), attn
 
     # ---- reference-compatible API -------------------------------------------------------------
     def generate(self, images: torch.Tensor, vocab, max_len: int, device, temp: Optional[float], beam_size: int,

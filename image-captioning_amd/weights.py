@@ -49,6 +49,17 @@ def matrix(w: torch.Tensor, dtype: torch.dtype, device, k_pad: Optional[int] = N
     return out.to(device=device, dtype=dtype).contiguous()
 
 
+def frag_matrix(w: torch.Tensor, dtype: torch.dtype, device) -> torch.Tensor:
+    """[N][K] -> MFMA fragment order [N/16][K/e][4 chunks][16 rows][16 bytes] (what mic_pack_weight_frag
+    writes): each 16-row x 64-byte tile becomes 1 KiB contiguous in lane order."""
+    n, k = w.shape
+    e = k_multiple(dtype)
+    if n % 16 or k % e:
+        raise ValueError(f"fragment packing needs N % 16 == 0 and K % {e} == 0, got {n}x{k}")
+    t = w.float().to(dtype).view(n // 16, 16, k // e, 4, e // 4).permute(0, 2, 3, 1, 4).contiguous()
+    return t.to(device)
+
+
 def vector(v: torch.Tensor, device) -> torch.Tensor:
     return v.detach().float().contiguous().to(device)
 
@@ -137,6 +148,11 @@ def build_tr_decoder(sd: SD, heads: int, dtype: torch.dtype, device) -> tuple:
         Y.cross_out_b = keep(vector(sd[p + "cross_attention.mha.out_proj.bias"], device))
         Y.ff1_w, Y.ff1_b = keep(matrix(sd[p + "ff.seq.0.weight"], dtype, device)), keep(vector(sd[p + "ff.seq.0.bias"], device))
         Y.ff2_w, Y.ff2_b = keep(matrix(sd[p + "ff.seq.2.weight"], dtype, device)), keep(vector(sd[p + "ff.seq.2.bias"], device))
+        e = k_multiple(dtype)
+        if L.lib.mic_linear_res_ln_supported(H) and H % e == 0:
+            Y.self_out_wf = keep(frag_matrix(sd[p + "self_attention.mha.out_proj.weight"], dtype, device))
+            Y.cross_out_wf = keep(frag_matrix(sd[p + "cross_attention.mha.out_proj.weight"], dtype, device))
+            Y.ff2_wf = keep(frag_matrix(sd[p + "ff.seq.2.weight"], dtype, device))
         for j, nm in enumerate(("self_attention", "cross_attention", "ff"), start=1):
             setattr(Y, f"ln{j}_g", keep(vector(sd[p + nm + ".layer_norm.weight"], device)))
             setattr(Y, f"ln{j}_b", keep(vector(sd[p + nm + ".layer_norm.bias"], device)))

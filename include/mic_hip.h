@@ -112,6 +112,23 @@ int mic_embed_pos(const int32_t* ids, int ld_ids, int pos, const float* tok_emb,
 int mic_layernorm(const float* x, const float* gamma, const float* beta, float* y, void* yt, int ld_yt,
                   int dtype, int N, int H, void* stream);
 
+/* Fused tail of a post-LN transformer sub-layer in one launch:
+ *   y = LayerNorm(x W^T + bias + res) * gamma + beta,   eps 1e-5
+ * x [M][ld_x] in `dtype`; W is the [H][K] weight in FRAGMENT ORDER as written by
+ * mic_pack_weight_frag; res fp32 [M][ld_res] (may alias y: each workgroup reads
+ * the rows it owns before writing them); writes fp32 y [M][H] and/or a `dtype` copy yt [M][ld_yt].
+ * Replaces out_proj / ff.seq.2 + the residual add + nn.LayerNorm (models/transformer.py:83-86,
+ * :136-140, :175-177) for the newest position.  Available for H in {64,128,256,512,1024}
+ * (mic_linear_res_ln_supported); other sizes use mic_conv2d + mic_layernorm. */
+int mic_linear_res_ln_supported(int H);
+/* [N][K] row-major weight -> [N/16][K/e][64][16 bytes] (e = elements per 64 bytes): the 1 KiB a
+ * wave loads as one MFMA operand (lane = (row & 15) + 16 * (16-byte chunk of the 64-byte k-tile))
+ * becomes contiguous.  Load-time layout change of nn.Linear weights; no reference counterpart. */
+int mic_pack_weight_frag(const void* w, void* out, int dtype, int N, int K, void* stream);
+int mic_linear_res_ln(const void* x, int ld_x, const void* w, const float* bias, const float* res, int ld_res,
+                      const float* gamma, const float* beta, float* y, void* yt, int ld_yt, int dtype, int M, int K, int H,
+                      void* stream);
+
 /* One new query per row against that row's cached keys/values, all heads
  * (the attention inside nn.MultiheadAttention, torch/nn/functional.py:6578-6606, for the last
  * text position only; the rest of the prefix is what the cache holds).
@@ -225,6 +242,10 @@ typedef struct mic_tr_layer {
     const void *self_in_w, *self_out_w, *cross_q_w, *cross_kv_w, *cross_out_w, *ff1_w, *ff2_w; /* dtype, padded */
     const float *self_in_b, *self_out_b, *cross_q_b, *cross_kv_b, *cross_out_b, *ff1_b, *ff2_b;
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+    /* optional: self_out_w / cross_out_w / ff2_w in fragment order (mic_pack_weight_frag).  When all
+     * three are set and the hidden size has a fused variant, the step driver runs
+     * mic_linear_res_ln instead of GEMM + LayerNorm for the three sub-layer tails. */
+    const void *self_out_wf, *cross_out_wf, *ff2_wf;
 } mic_tr_layer;
 
 typedef struct mic_tr_decoder {
@@ -269,16 +290,19 @@ int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int
 /* Steps [t0, t1) of transformer beam search on device: mic_tr_step, log-softmax top-K, beam
  * selection, ping-ponging between st[0] and st[1] (st[t & 1] is current at step t).
  * live_images: int32[t_cap] device counters, entry t receives the number of images with a live beam
- * after step t.  models/transformer.py:589-632. */
+ * after step t.  models/transformer.py:589-632.
+ * use_graph != 0: the run is captured into a HIP graph the first time a given argument set is seen
+ * (every pointer and size is part of the key) and replayed afterwards; the library keeps at most 32
+ * executables.  Capture instantiates a graph, i.e. allocates inside the runtime, on that first call. */
 int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const mic_beam_state st[2],
                       int32_t* parent, int32_t* live_images, const double* sqrt_tab, int B, int K,
-                      int t0, int t1, int eos_id, int want_attn, void* stream);
+                      int t0, int t1, int eos_id, int want_attn, int use_graph, void* stream);
 
 /* Steps [t0, t1) of batched greedy (u == NULL) or temperature sampling (u = uniforms [t_cap][N]).
  * models/transformer.py:490-547. */
 int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, int32_t* tokens,
                         uint8_t* finished, float* total, int32_t* live_rows, float inv_temp, const float* u,
-                        int t0, int t1, int pad_id, int eos_id, int want_attn, void* stream);
+                        int t0, int t1, int pad_id, int eos_id, int want_attn, int use_graph, void* stream);
 
 typedef struct mic_lstm_decoder {
     int32_t dtype, E, Hd, layers, vocab, kind; /* kind 0 = basic, 1 = intermediate */

@@ -386,3 +386,31 @@ def test_beam_select_first_step_uses_one_slot(L):
     # step does not fit the token buffer -> rejected, nothing launched
     assert L.lib.mic_beam_select(C.byref(cur), C.byref(nxt), tv.data_ptr(), ti.data_ptr(), parent.data_ptr(), None, sqrt_tab.data_ptr(),
                                  B, K, K, t_cap - 1, t_cap, 2, 0, L.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,H", [(5, 64, 64), (768, 512, 512), (33, 1024, 512), (100, 256, 256), (16, 128, 1024), (48, 256, 128)])
+def test_linear_res_ln_fused(L, W, dtype, M, K, H):
+    """y = LN(x W^T + b + res): the fused skinny kernel against torch, residual aliased with the output."""
+    g = torch.Generator().manual_seed(M + K + H)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(H, K, generator=g) / math.sqrt(K)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    b, res = torch.randn(H, generator=g), torch.randn(M, H, generator=g)
+    gam, bet = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    assert L.lib.mic_linear_res_ln_supported(H) == 1 and L.lib.mic_linear_res_ln_supported(192) == 0
+    xd, bd, gd, bed = x.to(DEV, dtype), b.to(DEV), gam.to(DEV), bet.to(DEV)
+    wrow = w.to(DEV, dtype).contiguous()
+    wd = torch.empty_like(wrow)  # fragment order, written by the library's own packer
+    L.check(L.lib.mic_pack_weight_frag(wrow.data_ptr(), wd.data_ptr(), L.dtype_code(dtype), H, K, L.stream_ptr()))
+    assert torch.equal(wd.view(-1), W.frag_matrix(w, dtype, DEV).view(-1))  # same layout as the host-side packer
+    y = res.to(DEV).clone()  # in place: res == y
+    yt = torch.empty(M, H, dtype=dtype, device=DEV)
+    L.check(L.lib.mic_linear_res_ln(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), H, gd.data_ptr(), bed.data_ptr(),
+                                    y.data_ptr(), yt.data_ptr(), H, L.dtype_code(dtype), M, K, H, L.stream_ptr()))
+    ref = F.layer_norm(x @ w.t() + b + res, (H,), gam, bet, 1e-5)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), **_tol(dtype))
+    np.testing.assert_allclose(yt.float().cpu().numpy(), ref.numpy(), **(_tol(dtype) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)))
+    assert L.lib.mic_linear_res_ln(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), H, gd.data_ptr(), bed.data_ptr(),
+                                   y.data_ptr(), yt.data_ptr(), H, L.dtype_code(dtype), M, K, 192, L.stream_ptr()) == -1

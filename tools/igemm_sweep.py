@@ -95,5 +95,32 @@ def main():
         print(f"{nm:12s} M={M:8d} N={N:5d} K={K:5d} {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "ln"):
     main()
+
+
+def fused_ln():
+    dt = torch.bfloat16
+    for (M, K, H) in [(768, 512, 512), (768, 1024, 512)]:
+        x = torch.randn(M, K, device=DEV).to(dt)
+        w = amd.weights.frag_matrix(torch.randn(H, K) * 0.05, dt, DEV)
+        b, g, be = torch.randn(H, device=DEV), torch.randn(H, device=DEV), torch.randn(H, device=DEV)
+        y = torch.randn(M, H, device=DEV)
+        yt = torch.empty(M, H, device=DEV, dtype=dt)
+
+        def call():
+            L.check(L.lib.mic_linear_res_ln(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), H, g.data_ptr(), be.data_ptr(),
+                                            y.data_ptr(), yt.data_ptr(), H, L.BF16, M, K, H, L.stream_ptr()))
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"gemm_res_ln  M={M} K={K} H={H}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ln":
+    fused_ln()
