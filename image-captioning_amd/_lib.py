@@ -28,6 +28,16 @@ class ConvDesc(C.Structure):
                 ("ldc", i32), ("ld_res", i32), ("relu", i32), ("k_valid", i32)]
 
 
+class LnRef(C.Structure):
+    _fields_ = [("raw", vp), ("stats", vp), ("gamma", vp), ("beta", vp), ("ld", i32), ("parts", i32), ("width", i32)]
+
+
+class SkinnyDesc(C.Structure):
+    _fields_ = [("x", vp), ("x_ln", LnRef), ("wf", vp), ("bias", vp), ("res", vp), ("res_ln", LnRef), ("out", vp), ("stats_out", vp),
+                ("dtype", i32), ("out_dtype", i32), ("ld_x", i32), ("ld_res", i32), ("ldc", i32), ("M", i32), ("N", i32), ("K", i32),
+                ("relu", i32)]
+
+
 class BeamState(C.Structure):
     _fields_ = [("score", vp), ("len", vp), ("seq", vp), ("anc", vp)]
 
@@ -47,19 +57,19 @@ _TR_LN = ["ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b"]
 
 
 class TrLayer(C.Structure):
-    _fields_ = [(n, vp) for n in _TR_W + _TR_B + _TR_LN + ["self_out_wf", "cross_out_wf", "ff2_wf"]]
+    _fields_ = [(n, vp) for n in _TR_W + _TR_B + _TR_LN + ["self_out_wf", "cross_out_wf", "ff2_wf", "self_in_wf", "cross_q_wf", "ff1_wf"]]
 
 
 class TrDecoder(C.Structure):
     _fields_ = [("dtype", i32), ("H", i32), ("heads", i32), ("layers", i32), ("vocab", i32), ("pos_rows", i32),
-                ("tok_emb", vp), ("pos_emb", vp), ("layer", TrLayer * MAX_LAYERS), ("out_w", vp), ("out_b", vp)]
+                ("tok_emb", vp), ("pos_emb", vp), ("layer", TrLayer * MAX_LAYERS), ("out_w", vp), ("out_b", vp), ("out_wf", vp)]
 
 
 class TrWorkspace(C.Structure):
     _fields_ = [("N", i32), ("t_cap", i32), ("S", i32), ("rows_per_image", i32),
                 ("x", vp), ("xt", vp), ("y", vp), ("qkv", vp), ("o", vp), ("ffh", vp), ("logits", vp),
                 ("kcache", vp * MAX_LAYERS), ("vcache", vp * MAX_LAYERS), ("cross_kv", vp * MAX_LAYERS),
-                ("attn", vp), ("top_val", vp), ("top_idx", vp)]
+                ("attn", vp), ("top_val", vp), ("top_idx", vp), ("stats", vp * 2)]
 
 
 class LstmDecoder(C.Structure):
@@ -87,6 +97,8 @@ SIGNATURES = {
     "mic_embed_pos": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_pack_weight_frag": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_linear_skinny": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_linear_skinny_ex": (C.c_int, [C.POINTER(SkinnyDesc), vp]),
     "mic_linear_res_ln_supported": (C.c_int, [C.c_int]),
     "mic_linear_res_ln": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_self_attn_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -88,9 +88,15 @@ struct AttnArgs {
     int N, H, heads;
 };
 
-template <typename T, bool SELF>
+// CPL = 16-byte chunks of one head's key row handled by one lane (head_dim / VEC / 16, rounded up).
+// Loads are issued in rounds of up to 8 per lane before anything consumes them: the value rows of
+// phase C do not depend on the softmax, so they are requested together with the first key rows and
+// the kernel pays about two dependent memory round trips instead of five.
+template <typename T, bool SELF, int CPL>
 __global__ __launch_bounds__(256) void attn_step_kernel(const AttnArgs a) {
     constexpr int VEC = Vec16<T>::N;
+    constexpr int RA = 8 / CPL;  // (head, position) pairs per lane-group per round
+    constexpr int RC = 8;        // value rows per thread per round
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = a.H, heads = a.heads, hd = H / heads;
     const int P = SELF ? a.t + 1 : a.S;
@@ -116,48 +122,74 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const AttnArgs a) {
     }
     __syncthreads();
 
-    // rows of keys / values for position p; position t of the self form comes from the fresh
-    // projection (rounded through T, i.e. exactly what was just written to the cache)
-    auto load_kv = [&](int p, int off, bool value, float (&f)[VEC]) {
+    // 16 bytes of the key / value row of position p at element offset off; position t of the self
+    // form comes from the fresh projection rounded through T (what was just written to the cache)
+    auto load_raw = [&](int p, int off, bool value) -> Vec16<T> {
         if constexpr (SELF) {
             if (p == a.t) {
                 const float* src = qrow + (value ? 2 * H : H) + off;
+                Vec16<T> r;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) f[e] = to_f32<T>(from_f32<T>(src[e]));
-                return;
+                for (int e = 0; e < VEC; ++e) r.v[e] = from_f32<T>(src[e]);
+                return r;
             }
-            const T* base = (const T*)(value ? a.vcache : a.kcache) + ((long long)anc_s[p] * a.t_cap + p) * H + off;
-            const Vec16<T> v = ld16(base);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) f[e] = to_f32<T>(v.v[e]);
+            return ld16((const T*)(value ? a.vcache : a.kcache) + ((long long)anc_s[p] * a.t_cap + p) * H + off);
         } else {
-            const T* base = (const T*)a.kv + ((long long)(n / a.rows_per_image) * a.S + p) * 2 * H + (value ? H : 0) + off;
-            const Vec16<T> v = ld16(base);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) f[e] = to_f32<T>(v.v[e]);
+            return ld16((const T*)a.kv + ((long long)(n / a.rows_per_image) * a.S + p) * 2 * H + (value ? H : 0) + off);
         }
     };
+
+    // value rows of the first phase-C round: requested now, consumed after the softmax
+    const int pg = tid / C, cc = tid - pg * C;
+    const bool c_active = pg < npg;
+    Vec16<T> vpre[RC];
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+        const int p = pg + i * npg;
+        if (c_active && p < P) vpre[i] = load_raw(p, cc * VEC, true);
+    }
 
     // phase A
     {
         const int grp = tid >> 4, gl = tid & 15;
         const int npairs = heads * P;
         const int chunks = hd / VEC;
-        for (int pair = grp; pair < npairs; pair += 16) {
-            const int h = pair / P, p = pair - h * P;
-            float s = 0.f;
-            for (int c = gl; c < chunks; c += 16) {
-                float f[VEC];
-                load_kv(p, h * hd + c * VEC, false, f);
-                const float* qq = q_s + h * hd + c * VEC;
+        for (int pair0 = grp; pair0 < npairs; pair0 += 16 * RA) {
+            Vec16<T> kraw[RA][CPL];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) s = fmaf(qq[e], f[e], s);
+            for (int i = 0; i < RA; ++i) {
+                const int pair = pair0 + 16 * i;
+                if (pair < npairs) {
+                    const int h = pair / P, p = pair - h * P;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int c = gl + 16 * j;
+                        if (c < chunks) kraw[i][j] = load_raw(p, h * hd + c * VEC, false);
+                    }
+                }
             }
-            s += __shfl_xor(s, 8, 16);
-            s += __shfl_xor(s, 4, 16);
-            s += __shfl_xor(s, 2, 16);
-            s += __shfl_xor(s, 1, 16);
-            if (gl == 0) sc[pair] = s;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int pair = pair0 + 16 * i;
+                if (pair < npairs) {  // uniform within the 16-lane group
+                    const int h = pair / P;
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int c = gl + 16 * j;
+                        if (c < chunks) {
+                            const float* qq = q_s + h * hd + c * VEC;
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) s = fmaf(qq[e], to_f32<T>(kraw[i][j].v[e]), s);
+                        }
+                    }
+                    s += __shfl_xor(s, 8, 16);
+                    s += __shfl_xor(s, 4, 16);
+                    s += __shfl_xor(s, 2, 16);
+                    s += __shfl_xor(s, 1, 16);
+                    if (gl == 0) sc[pair] = s;
+                }
+            }
         }
     }
     __syncthreads();
@@ -193,23 +225,28 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const AttnArgs a) {
         }
     }
     // phase C
-    {
-        const int pg = tid / C, c = tid - pg * C;
-        if (pg < npg) {
-            const int h = (c * VEC) / hd;
-            float acc[VEC];
+    if (c_active) {
+        const int h = (cc * VEC) / hd;
+        float acc[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-            for (int p = pg; p < P; p += npg) {
-                float f[VEC];
-                load_kv(p, c * VEC, true, f);
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const int p = pg + i * npg;
+            if (p < P) {
                 const float wgt = sc[h * P + p];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, f[e], acc[e]);
+                for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, to_f32<T>(vpre[i].v[e]), acc[e]);
             }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) part[pg * H + c * VEC + e] = acc[e];
         }
+        for (int p = pg + RC * npg; p < P; p += npg) {  // positions beyond the prefetched round
+            const Vec16<T> v = load_raw(p, cc * VEC, true);
+            const float wgt = sc[h * P + p];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, to_f32<T>(v.v[e]), acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) part[pg * H + cc * VEC + e] = acc[e];
     }
     __syncthreads();
     T* orow = (T*)a.o + (long long)n * a.ld_o;
@@ -227,7 +264,11 @@ template <typename T, bool SELF> int launch_attn(const AttnArgs& a, hipStream_t 
     const int npg = 256 / C > 0 ? 256 / C : 1;
     const size_t lds = sizeof(float) * ((size_t)a.H + ((a.heads * P + 3) & ~3) + (size_t)npg * a.H) + sizeof(int) * (SELF ? P : 0);
     MIC_ARG_CHECK(lds <= 64 * 1024, "attention step: %zu bytes of LDS needed (H=%d heads=%d positions=%d)", lds, a.H, a.heads, P);
-    MIC_LAUNCH((attn_step_kernel<T, SELF>), dim3(a.N), dim3(256), lds, s, a);
+    const int cpl = (a.H / a.heads / VEC + 15) / 16;
+    if (cpl <= 1) MIC_LAUNCH((attn_step_kernel<T, SELF, 1>), dim3(a.N), dim3(256), lds, s, a);
+    else if (cpl <= 2) MIC_LAUNCH((attn_step_kernel<T, SELF, 2>), dim3(a.N), dim3(256), lds, s, a);
+    else if (cpl <= 4) MIC_LAUNCH((attn_step_kernel<T, SELF, 4>), dim3(a.N), dim3(256), lds, s, a);
+    else MIC_LAUNCH((attn_step_kernel<T, SELF, 8>), dim3(a.N), dim3(256), lds, s, a);
     return 0;
 }
 
@@ -237,6 +278,7 @@ int check_attn_dims(const char* who, int dtype, int N, int H, int heads) {
     const int vec = 16 / (int)mic_dtype_size(dtype);
     MIC_ARG_CHECK((H / heads) % vec == 0, "%s: head_dim=%d must be a multiple of %d", who, H / heads, vec);
     MIC_ARG_CHECK(H / vec <= 256, "%s: H=%d too large for one workgroup per row", who, H);
+    MIC_ARG_CHECK(H / heads / vec <= 128, "%s: head_dim=%d too large", who, H / heads);
     return 0;
 }
 

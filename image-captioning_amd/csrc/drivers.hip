@@ -188,6 +188,14 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
 // transformer decoder
 // ---------------------------------------------------------------------------------------------
 namespace {
+// y = act(in W^T + b): skinny weight-streaming kernel for small row counts when a fragment-ordered
+// copy of the weights exists, tiled implicit-GEMM kernel otherwise
+int proj(int dt, const void* wf, const void* in, int ld_in, int N_rows, int K, const void* w, const float* b, void* out, int out_dt,
+         int ldc, int N_cols, int relu, hipStream_t s) {
+    if (wf && N_rows <= 2048) return mic_linear_skinny(in, ld_in, wf, b, out, out_dt, ldc, dt, N_rows, N_cols, K, relu, s);
+    return linear(dt, in, ld_in, N_rows, K, w, b, nullptr, 0, 0, out, out_dt, ldc, N_cols, relu, s);
+}
+
 // x <- LayerNorm(in W^T + b + x): one fused launch when the hidden size has a fused variant,
 // otherwise GEMM (+bias +residual) into y followed by the LayerNorm kernel
 int res_ln(int dt, const void* wf, const void* in, int ld_in, int K, const void* w, const float* b, const float* g, const float* be,
@@ -225,6 +233,86 @@ extern "C" int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace
     return 0;
 }
 
+namespace {
+mic_ln_ref ln_view(const float* raw, const float* stats, const float* g, const float* b, int H) {
+    mic_ln_ref v{};
+    v.raw = raw; v.stats = stats; v.gamma = g; v.beta = b; v.ld = H; v.parts = (H + 127) / 128; v.width = H;
+    return v;
+}
+
+// One decoder step with every LayerNorm folded into its neighbours (mic_linear_skinny_ex): the
+// sub-layer tails store the pre-norm sum y and its row statistics, the next projection and the next
+// residual add normalise on load.  8 launches per layer, none narrower than (N/16) x (H/128) workgroups.
+int tr_step_chained(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
+                    int attn_mode, hipStream_t s) {
+    const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
+    MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
+    bool plain = true;  // x is ws->x / ws->xt; otherwise x = LN(ws->y; ws->stats[cs]) with (pg, pb)
+    int cs = 0;
+    const float *pg = nullptr, *pb = nullptr;
+    auto base = [&](const void* wf, const float* bias, int K, int Ncols) {
+        mic_skinny_desc d{};
+        d.wf = wf; d.bias = bias; d.dtype = dt; d.M = N; d.N = Ncols; d.K = K;
+        return d;
+    };
+    auto set_x = [&](mic_skinny_desc& d) {  // input = current x
+        if (plain) { d.x = ws->xt; d.ld_x = H; }
+        else d.x_ln = ln_view(ws->y, ws->stats[cs], pg, pb, H);
+    };
+    auto tail = [&](const void* in, int ld_in, int K, const void* wf, const float* bias, const float* g, const float* b) -> int {
+        // y <- in W^T + bias + x ; statistics of y ; afterwards x = LN(y) with (g, b)
+        mic_skinny_desc d = base(wf, bias, K, H);
+        d.x = in; d.ld_x = ld_in;
+        if (plain) { d.res = ws->x; d.ld_res = H; }
+        else d.res_ln = ln_view(ws->y, ws->stats[cs], pg, pb, H);
+        const int ns = plain ? 0 : cs ^ 1;
+        d.out = ws->y; d.out_dtype = MIC_F32; d.ldc = H; d.stats_out = ws->stats[ns];
+        MIC_TRY(mic_linear_skinny_ex(&d, s));
+        plain = false; cs = ns; pg = g; pb = b;
+        return 0;
+    };
+    for (int l = 0; l < L; ++l) {
+        const mic_tr_layer& Y = dec->layer[l];
+        {
+            mic_skinny_desc d = base(Y.self_in_wf, Y.self_in_b, H, 3 * H);
+            set_x(d);
+            d.out = ws->qkv; d.out_dtype = MIC_F32; d.ldc = 3 * H;
+            MIC_TRY(mic_linear_skinny_ex(&d, s));
+        }
+        MIC_TRY(mic_self_attn_step(ws->qkv, ws->kcache[l], ws->vcache[l], anc, t, ws->t_cap, ws->o, H, dt, N, H, dec->heads, s));
+        MIC_TRY(tail(ws->o, H, H, Y.self_out_wf, Y.self_out_b, Y.ln1_g, Y.ln1_b));
+        {
+            mic_skinny_desc d = base(Y.cross_q_wf, Y.cross_q_b, H, H);
+            set_x(d);
+            d.out = ws->qkv; d.out_dtype = MIC_F32; d.ldc = H;
+            MIC_TRY(mic_linear_skinny_ex(&d, s));
+        }
+        float* ap = nullptr;
+        int ld_attn = 0, accumulate = 0;
+        float scale = 1.f;
+        if (attn_mode == 1) {
+            ap = ws->attn + (int64_t)t * S; ld_attn = ws->t_cap * S; scale = 1.f / (float)L; accumulate = l > 0;
+        } else if (attn_mode == 2) {
+            ap = ws->attn + ((int64_t)l * ws->t_cap + t) * N * S; ld_attn = S;
+        }
+        MIC_TRY(mic_cross_attn_step(ws->qkv, H, ws->cross_kv[l], S, ws->rows_per_image, ws->o, H, ap, ld_attn, scale, accumulate, dt,
+                                    N, H, dec->heads, s));
+        MIC_TRY(tail(ws->o, H, H, Y.cross_out_wf, Y.cross_out_b, Y.ln2_g, Y.ln2_b));
+        {
+            mic_skinny_desc d = base(Y.ff1_wf, Y.ff1_b, H, 2 * H);
+            set_x(d);
+            d.out = ws->ffh; d.out_dtype = dt; d.ldc = 2 * H; d.relu = 1;
+            MIC_TRY(mic_linear_skinny_ex(&d, s));
+        }
+        MIC_TRY(tail(ws->ffh, 2 * H, 2 * H, Y.ff2_wf, Y.ff2_b, Y.ln3_g, Y.ln3_b));
+    }
+    mic_skinny_desc d = base(dec->out_wf, dec->out_b, H, dec->vocab);
+    set_x(d);
+    d.out = ws->logits; d.out_dtype = MIC_F32; d.ldc = dec->vocab;
+    return mic_linear_skinny_ex(&d, s);
+}
+}  // namespace
+
 extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
                            const int32_t* anc, int t, int attn_mode, void* stream) {
     MIC_TRY(check_tr(dec, ws));
@@ -233,16 +321,22 @@ extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws
     MIC_ARG_CHECK(attn_mode == 0 || ws->attn, "mic_tr_step: attention requested without a buffer");
     hipStream_t s = (hipStream_t)stream;
     const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
+    bool chain = N <= 2048 && ws->stats[0] && ws->stats[1] && dec->out_wf && H % 4 == 0 && H <= 1024;
+    for (int l = 0; l < L && chain; ++l) {
+        const mic_tr_layer& Y = dec->layer[l];
+        chain = Y.self_in_wf && Y.self_out_wf && Y.cross_q_wf && Y.cross_out_wf && Y.ff1_wf && Y.ff2_wf;
+    }
+    if (chain) return tr_step_chained(dec, ws, tokens, ld_tok, anc, t, attn_mode, s);
     const bool fused = mic_linear_res_ln_supported(H) != 0;
     MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
     for (int l = 0; l < L; ++l) {
         const mic_tr_layer& Y = dec->layer[l];
         // masked self-attention over the cache + residual + LayerNorm
-        MIC_TRY(linear(dt, ws->xt, H, N, H, Y.self_in_w, Y.self_in_b, nullptr, 0, 0, ws->qkv, MIC_F32, 3 * H, 3 * H, 0, s));
+        MIC_TRY(proj(dt, Y.self_in_wf, ws->xt, H, N, H, Y.self_in_w, Y.self_in_b, ws->qkv, MIC_F32, 3 * H, 3 * H, 0, s));
         MIC_TRY(mic_self_attn_step(ws->qkv, ws->kcache[l], ws->vcache[l], anc, t, ws->t_cap, ws->o, H, dt, N, H, dec->heads, s));
         MIC_TRY(res_ln(dt, fused ? Y.self_out_wf : nullptr, ws->o, H, H, Y.self_out_w, Y.self_out_b, Y.ln1_g, Y.ln1_b, ws, N, H, s));
         // cross-attention against the image's cached K/V + residual + LayerNorm
-        MIC_TRY(linear(dt, ws->xt, H, N, H, Y.cross_q_w, Y.cross_q_b, nullptr, 0, 0, ws->qkv, MIC_F32, H, H, 0, s));
+        MIC_TRY(proj(dt, Y.cross_q_wf, ws->xt, H, N, H, Y.cross_q_w, Y.cross_q_b, ws->qkv, MIC_F32, H, H, 0, s));
         float* ap = nullptr;
         int ld_attn = 0, accumulate = 0;
         float scale = 1.f;
@@ -255,10 +349,10 @@ extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws
                                     N, H, dec->heads, s));
         MIC_TRY(res_ln(dt, fused ? Y.cross_out_wf : nullptr, ws->o, H, H, Y.cross_out_w, Y.cross_out_b, Y.ln2_g, Y.ln2_b, ws, N, H, s));
         // feed-forward + residual + LayerNorm
-        MIC_TRY(linear(dt, ws->xt, H, N, H, Y.ff1_w, Y.ff1_b, nullptr, 0, 0, ws->ffh, dt, 2 * H, 2 * H, 1, s));
+        MIC_TRY(proj(dt, Y.ff1_wf, ws->xt, H, N, H, Y.ff1_w, Y.ff1_b, ws->ffh, dt, 2 * H, 2 * H, 1, s));
         MIC_TRY(res_ln(dt, fused ? Y.ff2_wf : nullptr, ws->ffh, 2 * H, 2 * H, Y.ff2_w, Y.ff2_b, Y.ln3_g, Y.ln3_b, ws, N, H, s));
     }
-    return linear(dt, ws->xt, H, N, H, dec->out_w, dec->out_b, nullptr, 0, 0, ws->logits, MIC_F32, dec->vocab, dec->vocab, 0, s);
+    return proj(dt, dec->out_wf, ws->xt, H, N, H, dec->out_w, dec->out_b, ws->logits, MIC_F32, dec->vocab, dec->vocab, 0, s);
 }
 
 extern "C" int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const mic_beam_state st[2], int32_t* parent,

@@ -159,6 +159,257 @@ __global__ __launch_bounds__(NW * 64) void gemm_res_ln_kernel(const GemmLnArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM, general form:  out = act(X W^T + bias + R), same operand streaming, where X and R may
+// each be a *LayerNorm view* of a raw fp32 matrix: LN(raw)*gamma+beta evaluated while the rows are
+// staged (X) or added (R), from per-row partial statistics the producing launch left behind.  A
+// launch can in turn emit those statistics for its own output (mean and centred sum of squares of
+// each row over the workgroup's 128 columns).  Chained this way, a post-LN transformer layer needs
+// no LayerNorm launch and no launch narrower than (rows/16) x (N/128) workgroups:
+//      y, stats = X W^T + b + LN(y_prev)        (producer: plain stores, end of launch)
+//      q        = LN(y; stats) Wq^T + bq        (consumer: next launch)
+// Partial statistics are combined with the pairwise update of Chan et al., so the result has
+// two-pass accuracy.  A workgroup (4 waves) owns MT*16 rows and 128 columns (2 tiles per wave).
+struct LnRef {
+    const float* raw;
+    const float* stats;
+    const float *gamma, *beta;
+    int ld, parts, width;
+};
+struct SkinnyArgs {
+    const void* x;
+    LnRef xl;
+    const void* w;
+    const float* bias;
+    const float* res;
+    LnRef rl;
+    void* out;
+    float* stats_out;
+    int ld_x, ld_res, ldc, M, N, K, relu, out_dtype, col_blocks;
+};
+
+// mean and 1/sqrt(var + eps) of one row from its per-part (mean, M2) pairs
+__device__ __forceinline__ void merge_row_stats(const LnRef& l, int m, float& mean, float& rstd) {
+    const float* st = l.stats + (long long)m * l.parts * 2;
+    float n = 0.f, mu = 0.f, m2 = 0.f;
+    for (int p = 0; p < l.parts; ++p) {
+        const float nb = (float)min(128, l.width - 128 * p), mb = st[2 * p], sb = st[2 * p + 1];
+        const float nt = n + nb, d = mb - mu;
+        mu += d * (nb / nt);
+        m2 += sb + d * d * (n * nb / nt);
+        n = nt;
+    }
+    mean = mu;
+    rstd = 1.0f / sqrtf(m2 / n + 1e-5f);
+}
+
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T), EPR = 4 * VEC, TPW = 2, U = 4, ROWS = MT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
+    __shared__ float rs_x[ROWS][2], rs_r[ROWS][2], red[2][4][ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int cb = blockIdx.x % a.col_blocks, rb = blockIdx.x / a.col_blocks;
+    const int m0 = rb * ROWS, nb = cb * 128 + wave * TPW * 16;
+    const int nk = a.K / EPR;
+    const int xrow = a.K * (int)sizeof(T) + 16;
+    if (tid < ROWS) {
+        const int mr = m0 + tid < a.M ? m0 + tid : a.M - 1;
+        if (a.xl.raw) merge_row_stats(a.xl, mr, rs_x[tid][0], rs_x[tid][1]);
+        if (a.rl.raw) merge_row_stats(a.rl, mr, rs_r[tid][0], rs_r[tid][1]);
+    }
+    if (a.xl.raw) __syncthreads();
+    {
+        const int cpr = a.K / VEC;
+        for (int c = tid; c < ROWS * cpr; c += 256) {
+            const int row = c / cpr, ch = c - row * cpr;
+            const int mr = m0 + row < a.M ? m0 + row : a.M - 1;
+            if (a.xl.raw) {
+                const float mean = rs_x[row][0], rstd = rs_x[row][1];
+                const float* src = a.xl.raw + (long long)mr * a.xl.ld + ch * VEC;
+                Vec16<T> o;
+#pragma unroll
+                for (int e4 = 0; e4 < VEC; e4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + e4);
+                    const float4 g = *reinterpret_cast<const float4*>(a.xl.gamma + ch * VEC + e4);
+                    const float4 b = *reinterpret_cast<const float4*>(a.xl.beta + ch * VEC + e4);
+                    o.v[e4 + 0] = from_f32<T>((v.x - mean) * rstd * g.x + b.x);
+                    o.v[e4 + 1] = from_f32<T>((v.y - mean) * rstd * g.y + b.y);
+                    o.v[e4 + 2] = from_f32<T>((v.z - mean) * rstd * g.z + b.z);
+                    o.v[e4 + 3] = from_f32<T>((v.w - mean) * rstd * g.w + b.w);
+                }
+                st16(reinterpret_cast<T*>(xs + row * xrow + ch * 16), o);
+            } else {
+                *reinterpret_cast<uint4*>(xs + row * xrow + ch * 16) = *reinterpret_cast<const uint4*>((const T*)a.x + (long long)mr * a.ld_x + ch * VEC);
+            }
+        }
+    }
+    const unsigned char* xp = xs + r * xrow + q * 16;
+    const T* wp = (const T*)a.w + ((long long)(nb / 16) * nk * 64 + lane) * VEC;
+    __syncthreads();
+
+    f32x4_t acc[MT][TPW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 wa[U][TPW], wb[U][TPW];
+    auto load_w = [&](int kt0, uint4 (&wf)[U][TPW]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt0 + u < nk ? kt0 + u : nk - 1;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) wf[u][j] = *reinterpret_cast<const uint4*>(wp + ((long long)j * nk + kt) * 64 * VEC);
+        }
+    };
+    auto mma_group = [&](int kt0, const uint4 (&wf)[U][TPW]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kt0 + u < nk) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const uint4 xf = *reinterpret_cast<const uint4*>(xp + i * 16 * xrow + (kt0 + u) * 64);
+#pragma unroll
+                    for (int j = 0; j < TPW; ++j) SkinnyMma<T>::run(wf[u][j], xf, acc[i][j]);
+                }
+            }
+        }
+    };
+    load_w(0, wa);
+    for (int kt = 0; kt < nk; kt += 2 * U) {
+        load_w(kt + U, wb);
+        mma_group(kt, wa);
+        load_w(kt + 2 * U, wa);
+        mma_group(kt + U, wb);
+    }
+
+    // epilogue values: lane holds columns nb + j*16 + q*4 + e of rows m0 + i*16 + r
+    float v[MT][TPW][4];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int n = nb + j * 16 + q * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f}, bev[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e < a.N) {
+                if (a.bias) bv[e] = a.bias[n + e];
+                if (a.rl.raw) { gv[e] = a.rl.gamma[n + e]; bev[e] = a.rl.beta[n + e]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + i * 16 + r, mc = m < a.M ? m : a.M - 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[i][j][e] + bv[e];
+                if (n + e < a.N) {
+                    if (a.res) x += a.res[(long long)mc * a.ld_res + n + e];
+                    if (a.rl.raw) x += (a.rl.raw[(long long)mc * a.rl.ld + n + e] - rs_r[i * 16 + r][0]) * rs_r[i * 16 + r][1] * gv[e] + bev[e];
+                } else {
+                    x = 0.f;
+                }
+                v[i][j][e] = a.relu ? fmaxf(x, 0.f) : x;
+            }
+        }
+    }
+    if (a.stats_out) {
+        // per row: mean and centred sum of squares over this workgroup's valid columns
+        const float cnt = (float)min(128, a.N - cb * 128);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) s += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (q == 0) red[0][wave][i * 16 + r] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = i * 16 + r;
+            const float mean = ((red[0][0][row] + red[0][1][row]) + (red[0][2][row] + red[0][3][row])) / cnt;
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const int n = nb + j * 16 + q * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = n + e < a.N ? v[i][j][e] - mean : 0.f;
+                    sq = fmaf(d, d, sq);
+                }
+            }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (q == 0) red[1][wave][row] = sq;
+        }
+        __syncthreads();
+        if (tid < ROWS && m0 + tid < a.M) {
+            const float mean = ((red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid])) / cnt;
+            const float m2 = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+            float* dst = a.stats_out + ((long long)(m0 + tid) * a.col_blocks + cb) * 2;
+            dst[0] = mean;
+            dst[1] = m2;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int n = nb + j * 16 + q * 4;
+        if (n >= a.N) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + i * 16 + r;
+            if (m >= a.M) continue;
+            const bool full = n + 3 < a.N && (a.ldc & 3) == 0;
+            if (a.out_dtype == MIC_F32) {
+                float* o = (float*)a.out + (long long)m * a.ldc + n;
+                if (full) *reinterpret_cast<float4*>(o) = make_float4(v[i][j][0], v[i][j][1], v[i][j][2], v[i][j][3]);
+                else
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) o[e] = v[i][j][e];
+            } else {
+                bf16_t* o = (bf16_t*)a.out + (long long)m * a.ldc + n;
+                if (full) {
+                    struct alignas(8) B4 { bf16_t v[4]; } p;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p.v[e] = (bf16_t)v[i][j][e];
+                    *reinterpret_cast<B4*>(o) = p;
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) o[e] = (bf16_t)v[i][j][e];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int MT> int launch_skinny(SkinnyArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)MT * 16 * ((size_t)a.K * sizeof(T) + 16);
+    MIC_ARG_CHECK(lds <= 140 * 1024, "mic_linear_skinny: K=%d needs %zu bytes of LDS", a.K, lds);
+    if (lds > 48 * 1024) {
+        static bool granted = false;
+        if (!granted) {
+            MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<T, MT>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            granted = true;
+        }
+    }
+    a.col_blocks = (a.N + 127) / 128;
+    const int grid = a.col_blocks * ((a.M + MT * 16 - 1) / (MT * 16));
+    MIC_LAUNCH((skinny_gemm_kernel<T, MT>), dim3(grid), dim3(256), lds, s, a);
+    return 0;
+}
+
+int check_ln_ref(const char* who, const mic_ln_ref& l, int width) {
+    if (!l.raw) return 0;
+    MIC_ARG_CHECK(l.stats && l.gamma && l.beta, "%s: LayerNorm view without stats/gamma/beta", who);
+    MIC_ARG_CHECK(l.width == width && l.width % 4 == 0 && l.ld >= l.width && l.ld % 4 == 0 && l.parts == (l.width + 127) / 128,
+                  "%s: LayerNorm view of width %d (ld %d, %d parts) does not match %d columns", who, l.width, l.ld, l.parts, width);
+    MIC_ARG_CHECK(((uintptr_t)l.raw & 15) == 0 && ((uintptr_t)l.gamma & 15) == 0 && ((uintptr_t)l.beta & 15) == 0, "%s: 16-byte alignment", who);
+    return 0;
+}
+
 template <typename T, int NW, int TPW> int launch_gl(const GemmLnArgs& a, hipStream_t s) {
     const size_t lds = 16 * ((size_t)a.K * sizeof(T) + 16);
     MIC_ARG_CHECK(lds <= 150 * 1024, "mic_linear_res_ln: K=%d needs %zu bytes of LDS", a.K, lds);
@@ -194,8 +445,8 @@ template <typename T> int dispatch_gl(const GemmLnArgs& a, hipStream_t s) {
         case 64: return launch_gl<T, 4, 1>(a, s);
         case 128: return launch_gl<T, 8, 1>(a, s);
         case 256: return launch_gl<T, 8, 2>(a, s);
-        case 512: return launch_gl<T, 8, 4>(a, s);
-        case 1024: return launch_gl<T, 8, 8>(a, s);
+        case 512: return launch_gl<T, 16, 2>(a, s);  // 16 waves: twice the loads in flight per workgroup
+        case 1024: return launch_gl<T, 16, 4>(a, s);
         default: mic_set_error("mic_linear_res_ln: hidden size %d has no fused variant", a.H); return MIC_ERR_ARG;
     }
 }
@@ -214,6 +465,39 @@ extern "C" int mic_pack_weight_frag(const void* w, void* out, int dtype, int N, 
     else
         MIC_LAUNCH(pack_weight_frag_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)w, (float*)out, N, K);
     return 0;
+}
+
+extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) {
+    MIC_ARG_CHECK(d && d->wf && d->out && (d->x || d->x_ln.raw), "mic_linear_skinny: null pointer");
+    MIC_ARG_CHECK((d->dtype == MIC_F32 || d->dtype == MIC_BF16) && (d->out_dtype == MIC_F32 || d->out_dtype == MIC_BF16),
+                  "mic_linear_skinny: bad dtype");
+    const int epr = 64 / (int)mic_dtype_size(d->dtype);
+    MIC_ARG_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->K % epr == 0 && d->ldc >= d->N, "mic_linear_skinny: bad sizes M=%d N=%d K=%d ldc=%d",
+                  d->M, d->N, d->K, d->ldc);
+    MIC_ARG_CHECK(d->x_ln.raw || (d->ld_x >= d->K && d->ld_x % (epr / 4) == 0 && ((uintptr_t)d->x & 15) == 0), "mic_linear_skinny: bad x / ld_x=%d", d->ld_x);
+    MIC_ARG_CHECK(((uintptr_t)d->wf & 15) == 0 && ((uintptr_t)d->out & 15) == 0, "mic_linear_skinny: 16-byte alignment");
+    MIC_ARG_CHECK(!d->res || d->ld_res >= d->N, "mic_linear_skinny: ld_res=%d", d->ld_res);
+    MIC_ARG_CHECK(!(d->stats_out && d->relu), "mic_linear_skinny: statistics of a ReLU output are not supported");
+    MIC_TRY(check_ln_ref("mic_linear_skinny(x_ln)", d->x_ln, d->K));
+    MIC_TRY(check_ln_ref("mic_linear_skinny(res_ln)", d->res_ln, d->N));
+    SkinnyArgs a{};
+    a.x = d->x; a.w = d->wf; a.bias = d->bias; a.res = d->res; a.out = d->out; a.stats_out = d->stats_out;
+    a.xl = LnRef{d->x_ln.raw, d->x_ln.stats, d->x_ln.gamma, d->x_ln.beta, d->x_ln.ld, d->x_ln.parts, d->x_ln.width};
+    a.rl = LnRef{d->res_ln.raw, d->res_ln.stats, d->res_ln.gamma, d->res_ln.beta, d->res_ln.ld, d->res_ln.parts, d->res_ln.width};
+    a.ld_x = d->ld_x; a.ld_res = d->ld_res; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K; a.relu = d->relu; a.out_dtype = d->out_dtype;
+    hipStream_t s = (hipStream_t)stream;
+    // two row tiles per workgroup halve the weight traffic once there are enough workgroups to fill the chip
+    const long long blocks2 = (long long)((d->N + 127) / 128) * ((d->M + 31) / 32);
+    if (blocks2 >= 512) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 2>(a, s) : launch_skinny<float, 2>(a, s);
+    return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 1>(a, s) : launch_skinny<float, 1>(a, s);
+}
+
+extern "C" int mic_linear_skinny(const void* x, int ld_x, const void* wf, const float* bias, void* out, int out_dtype, int ldc,
+                                 int dtype, int M, int N, int K, int relu, void* stream) {
+    mic_skinny_desc d{};
+    d.x = x; d.ld_x = ld_x; d.wf = wf; d.bias = bias; d.out = out; d.out_dtype = out_dtype; d.ldc = ldc;
+    d.dtype = dtype; d.M = M; d.N = N; d.K = K; d.relu = relu;
+    return mic_linear_skinny_ex(&d, stream);
 }
 
 extern "C" int mic_linear_res_ln_supported(int H) { return H == 64 || H == 128 || H == 256 || H == 512 || H == 1024; }

@@ -87,6 +87,7 @@ class ImageCaptioner:
             "kc": torch.zeros(Ly, N, t_cap, H, dtype=d, device=dev), "vc": torch.zeros(Ly, N, t_cap, H, dtype=d, device=dev),
             "ckv": torch.empty(Ly, N // rpi, S, 2 * H, dtype=d, device=dev),
             "top_val": torch.empty(N, K, dtype=f32, device=dev), "top_idx": torch.empty(N, K, dtype=torch.int32, device=dev),
+            "stats": torch.zeros(2, N, (H + 127) // 128, 2, dtype=f32, device=dev),
         }
         if attn_mode == 1:
             t["attn"] = torch.zeros(N, t_cap, S, dtype=f32, device=dev)
@@ -99,6 +100,7 @@ class ImageCaptioner:
         for l in range(Ly):
             ws.kcache[l], ws.vcache[l], ws.cross_kv[l] = t["kc"][l].data_ptr(), t["vc"][l].data_ptr(), t["ckv"][l].data_ptr()
         ws.attn = t["attn"].data_ptr() if attn_mode else None
+        ws.stats[0], ws.stats[1] = t["stats"][0].data_ptr(), t["stats"][1].data_ptr()
         if len(self._ws_cache) > 4:
             self._ws_cache.clear()
         self._ws_cache[key] = (ws, t)

@@ -60,6 +60,15 @@ def frag_matrix(w: torch.Tensor, dtype: torch.dtype, device) -> torch.Tensor:
     return t.to(device)
 
 
+def _pad_rows(w: torch.Tensor, mult: int = ROW_PAD) -> torch.Tensor:
+    n = _round_up(w.shape[0], mult)
+    if n == w.shape[0]:
+        return w
+    out = torch.zeros(n, w.shape[1], dtype=w.dtype)
+    out[: w.shape[0]] = w
+    return out
+
+
 def vector(v: torch.Tensor, device) -> torch.Tensor:
     return v.detach().float().contiguous().to(device)
 
@@ -153,11 +162,18 @@ def build_tr_decoder(sd: SD, heads: int, dtype: torch.dtype, device) -> tuple:
             Y.self_out_wf = keep(frag_matrix(sd[p + "self_attention.mha.out_proj.weight"], dtype, device))
             Y.cross_out_wf = keep(frag_matrix(sd[p + "cross_attention.mha.out_proj.weight"], dtype, device))
             Y.ff2_wf = keep(frag_matrix(sd[p + "ff.seq.2.weight"], dtype, device))
+        if H % e == 0:  # fragment-ordered copies (rows zero-padded to 128) for the skinny GEMM
+            ipw = sd[p + "self_attention.mha.in_proj_weight"]
+            Y.self_in_wf = keep(frag_matrix(_pad_rows(ipw), dtype, device))
+            Y.cross_q_wf = keep(frag_matrix(_pad_rows(sd[p + "cross_attention.mha.in_proj_weight"][:H]), dtype, device))
+            Y.ff1_wf = keep(frag_matrix(_pad_rows(sd[p + "ff.seq.0.weight"]), dtype, device))
         for j, nm in enumerate(("self_attention", "cross_attention", "ff"), start=1):
             setattr(Y, f"ln{j}_g", keep(vector(sd[p + nm + ".layer_norm.weight"], device)))
             setattr(Y, f"ln{j}_b", keep(vector(sd[p + nm + ".layer_norm.bias"], device)))
     dec.out_w = keep(matrix(sd["output_layer.linear.weight"], dtype, device))
     dec.out_b = keep(vector(sd["output_layer.linear.bias"], device))
+    if H % k_multiple(dtype) == 0:
+        dec.out_wf = keep(frag_matrix(_pad_rows(sd["output_layer.linear.weight"]), dtype, device))
     return dec, keep
 
 

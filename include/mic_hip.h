@@ -129,6 +129,42 @@ int mic_linear_res_ln(const void* x, int ld_x, const void* w, const float* bias,
                       const float* gamma, const float* beta, float* y, void* yt, int ld_yt, int dtype, int M, int K, int H,
                       void* stream);
 
+/* out[M][ldc] = act(x W^T + bias) for a few hundred rows: workgroups of 16/32 rows x 128 columns
+ * stream fragment-ordered weights (mic_pack_weight_frag of the [N padded to 128][K] matrix, padding
+ * rows zero) straight into MFMA operands.  Same math as mic_conv2d's linear case; used by the step
+ * drivers for the in-projections, ff.seq.0 and the vocabulary projection
+ * (models/transformer.py:83,136,175,293) when the row count is small. */
+int mic_linear_skinny(const void* x, int ld_x, const void* wf, const float* bias, void* out, int out_dtype, int ldc,
+                      int dtype, int M, int N, int K, int relu, void* stream);
+
+/* General form of the skinny GEMM:  out = act(X W^T + bias + R).  X and/or R may be a LayerNorm VIEW
+ * of a raw fp32 matrix, LN(raw) * gamma + beta (eps 1e-5), evaluated on the fly from per-row partial
+ * statistics: stats[m][p] = (mean, centred sum of squares) of raw[m][128p .. 128p+127].  A launch
+ * writes those statistics for its own fp32 output when stats_out != NULL ([M][ceil(N/128)][2]).
+ * Chaining launches this way removes every nn.LayerNorm launch of a post-LN decoder layer
+ * (models/transformer.py:86,140,177): the producer stores the pre-norm sum and its statistics, the
+ * consumers (next projection, next residual add) normalise while they load.  out may alias
+ * res_ln.raw (each element is read and written by the same thread). */
+typedef struct mic_ln_ref {
+    const float* raw;     /* [M][ld] pre-LayerNorm values, NULL = not a view */
+    const float* stats;   /* [M][parts][2] */
+    const float *gamma, *beta;
+    int32_t ld, parts, width;  /* parts == ceil(width / 128) */
+} mic_ln_ref;
+
+typedef struct mic_skinny_desc {
+    const void* x;        /* [M][ld_x] in dtype (used when x_ln.raw == NULL) */
+    mic_ln_ref x_ln;      /* x_ln.width == K */
+    const void* wf;       /* fragment-ordered [N padded to 128][K] weight */
+    const float* bias;
+    const float* res;     /* plain fp32 residual [M][ld_res] or NULL */
+    mic_ln_ref res_ln;    /* res_ln.width == N */
+    void* out;            /* [M][ldc] of out_dtype */
+    float* stats_out;     /* NULL, or [M][ceil(N/128)][2] (fp32 output, no ReLU) */
+    int32_t dtype, out_dtype, ld_x, ld_res, ldc, M, N, K, relu;
+} mic_skinny_desc;
+int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream);
+
 /* One new query per row against that row's cached keys/values, all heads
  * (the attention inside nn.MultiheadAttention, torch/nn/functional.py:6578-6606, for the last
  * text position only; the rest of the prefix is what the cache holds).
@@ -246,6 +282,9 @@ typedef struct mic_tr_layer {
      * three are set and the hidden size has a fused variant, the step driver runs
      * mic_linear_res_ln instead of GEMM + LayerNorm for the three sub-layer tails. */
     const void *self_out_wf, *cross_out_wf, *ff2_wf;
+    /* optional: self_in_w / cross_q_w / ff1_w (rows padded to 128) in fragment order for
+     * mic_linear_skinny; used when set and the row count is at most 2048. */
+    const void *self_in_wf, *cross_q_wf, *ff1_wf;
 } mic_tr_layer;
 
 typedef struct mic_tr_decoder {
@@ -255,6 +294,7 @@ typedef struct mic_tr_decoder {
     mic_tr_layer layer[MIC_MAX_LAYERS];
     const void* out_w;     /* dtype [vocab padded][H] */
     const float* out_b;
+    const void* out_wf;    /* optional: out_w in fragment order (see mic_tr_layer) */
 } mic_tr_decoder;
 
 /* Per-call decode workspace; every pointer is caller-allocated device memory of at least the
@@ -274,6 +314,8 @@ typedef struct mic_tr_workspace {
     float* attn;     /* NULL, or beam: [N][t_cap][S]; sampling: [layers][t_cap][N][S] */
     float* top_val;  /* [N][K] */
     int32_t* top_idx;
+    float* stats[2]; /* optional, each [N][ceil(H/128)][2]: row statistics for the LayerNorm-free step
+                        (used when set, N <= 2048 and every fragment-ordered weight is present) */
 } mic_tr_workspace;
 
 /* Cross-attention keys/values of every layer from image tokens feats [B][S][H] (dtype):

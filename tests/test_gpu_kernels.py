@@ -414,3 +414,75 @@ def test_linear_res_ln_fused(L, W, dtype, M, K, H):
     np.testing.assert_allclose(yt.float().cpu().numpy(), ref.numpy(), **(_tol(dtype) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)))
     assert L.lib.mic_linear_res_ln(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), H, gd.data_ptr(), bed.data_ptr(),
                                    y.data_ptr(), yt.data_ptr(), H, L.dtype_code(dtype), M, K, 192, L.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,relu,out_bf16", [(768, 1536, 512, 0, 0), (768, 3500, 512, 0, 0), (5, 200, 64, 0, 0), (100, 1024, 512, 1, 1),
+                                                 (33, 130, 128, 1, 0), (2048, 512, 256, 0, 0)])
+def test_linear_skinny(L, W, dtype, M, N, K, relu, out_bf16):
+    g = torch.Generator().manual_seed(M * 3 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    b = torch.randn(N, generator=g)
+    wf = W.frag_matrix(W._pad_rows(w), dtype, DEV)
+    xd, bd = x.to(DEV, dtype), b.to(DEV)
+    odt = torch.bfloat16 if out_bf16 else torch.float32
+    ldc = (N + 7) // 8 * 8 + 8  # a row stride larger than N
+    out = torch.full((M, ldc), 7.0, dtype=odt, device=DEV)
+    L.check(L.lib.mic_linear_skinny(xd.data_ptr(), K, wf.data_ptr(), bd.data_ptr(), out.data_ptr(), L.dtype_code(odt), ldc,
+                                    L.dtype_code(dtype), M, N, K, relu, L.stream_ptr()))
+    ref = x @ w.t() + b
+    if relu:
+        ref = F.relu(ref)
+    tol = _tol(dtype) if not out_bf16 else dict(rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(out[:, :N].float().cpu().numpy(), ref.numpy(), **tol)
+    assert (out[:, N:].float() == 7.0).all()  # nothing written past column N
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H", [(768, 512), (37, 64), (100, 320), (16, 1024)])
+def test_skinny_layernorm_chain(L, W, dtype, M, H):
+    """Two chained launches reproduce GEMM -> +residual -> LayerNorm -> GEMM:
+       y, stats = x0 W1^T + b1 + r   (statistics emitted per 128-column part)
+       z        = LN(y) W2^T + b2 + LN(y)   (input and residual both LayerNorm views of y, in place)."""
+    g = torch.Generator().manual_seed(M + H)
+
+    def rnd(*s, scale=1.0):
+        t = torch.randn(*s, generator=g) * scale
+        return t.to(dtype).float() if dtype == torch.bfloat16 else t
+
+    x0, w1, w2 = rnd(M, H), rnd(H, H, scale=H ** -0.5), rnd(H, H, scale=H ** -0.5)
+    b1, b2, r = torch.randn(H, generator=g), torch.randn(H, generator=g), torch.randn(M, H, generator=g) * 2 + 0.5
+    gam, bet = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    parts = (H + 127) // 128
+    code = L.dtype_code(dtype)
+    keep = dict(x0=x0.to(DEV, dtype), w1=W.frag_matrix(W._pad_rows(w1), dtype, DEV), w2=W.frag_matrix(W._pad_rows(w2), dtype, DEV),
+                b1=b1.to(DEV), b2=b2.to(DEV), r=r.to(DEV), g=gam.to(DEV), be=bet.to(DEV),
+                y=torch.empty(M, H, device=DEV), st=torch.zeros(2, M, parts, 2, device=DEV))
+    d = L.SkinnyDesc()
+    d.x, d.ld_x, d.wf, d.bias, d.res, d.ld_res = keep["x0"].data_ptr(), H, keep["w1"].data_ptr(), keep["b1"].data_ptr(), keep["r"].data_ptr(), H
+    d.out, d.stats_out, d.dtype, d.out_dtype, d.ldc, d.M, d.N, d.K = keep["y"].data_ptr(), keep["st"][0].data_ptr(), code, L.F32, H, M, H, H
+    L.check(L.lib.mic_linear_skinny_ex(C.byref(d), L.stream_ptr()))
+    y_ref = x0 @ w1.t() + b1 + r
+    np.testing.assert_allclose(keep["y"].cpu().numpy(), y_ref.numpy(), **_tol(dtype))
+    st = keep["st"][0].cpu()
+    for p in range(parts):
+        sl = y_ref[:, 128 * p: 128 * (p + 1)]
+        np.testing.assert_allclose(st[:, p, 0].numpy(), sl.mean(1).numpy(), rtol=1e-3, atol=2e-3)
+        np.testing.assert_allclose(st[:, p, 1].numpy(), ((sl - sl.mean(1, keepdim=True)) ** 2).sum(1).numpy(), rtol=2e-3, atol=2e-3)
+    # second launch: input and residual are LayerNorm views of y; output written over y
+    view = L.LnRef(keep["y"].data_ptr(), keep["st"][0].data_ptr(), keep["g"].data_ptr(), keep["be"].data_ptr(), H, parts, H)
+    d2 = L.SkinnyDesc()
+    d2.x_ln, d2.res_ln, d2.wf, d2.bias = view, view, keep["w2"].data_ptr(), keep["b2"].data_ptr()
+    d2.out, d2.stats_out, d2.dtype, d2.out_dtype, d2.ldc, d2.M, d2.N, d2.K = keep["y"].data_ptr(), keep["st"][1].data_ptr(), code, L.F32, H, M, H, H
+    L.check(L.lib.mic_linear_skinny_ex(C.byref(d2), L.stream_ptr()))
+    ln = F.layer_norm(y_ref, (H,), gam, bet, 1e-5)
+    ln_in = ln.to(dtype).float() if dtype == torch.bfloat16 else ln
+    z_ref = ln_in @ w2.t() + b2 + ln
+    np.testing.assert_allclose(keep["y"].cpu().numpy(), z_ref.numpy(), **(_tol(dtype) if dtype == torch.float32 else dict(rtol=3e-2, atol=5e-2)))
+    # rejected: view width that does not match K
+    bad = L.LnRef(keep["y"].data_ptr(), keep["st"][0].data_ptr(), keep["g"].data_ptr(), keep["be"].data_ptr(), H, parts, H + 4)
+    d2.x_ln = bad
+    assert L.lib.mic_linear_skinny_ex(C.byref(d2), L.stream_ptr()) == -1
