@@ -4,6 +4,8 @@
 // 16-byte (or 4-float) vector along the hidden axis.
 #include "mic_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -95,8 +97,9 @@ struct AttnArgs {
 template <typename T, bool SELF, int CPL>
 __global__ __launch_bounds__(256) void attn_step_kernel(const AttnArgs a) {
     constexpr int VEC = Vec16<T>::N;
-    constexpr int RA = 8 / CPL;  // (head, position) pairs per lane-group per round
-    constexpr int RC = 8;        // value rows per thread per round
+    constexpr int DEPTH = 8;                  // 16-byte loads in flight per lane per round
+    constexpr int RA = DEPTH / CPL > 0 ? DEPTH / CPL : 1;  // (head, position) pairs per lane-group per round
+    constexpr int RC = DEPTH;                              // value rows per thread requested up front
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = a.H, heads = a.heads, hd = H / heads;
     const int P = SELF ? a.t + 1 : a.S;
@@ -107,7 +110,17 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const AttnArgs a) {
     float* part = sc + ((heads * P + 3) & ~3);  // [npg][H]
     int* anc_s = reinterpret_cast<int*>(part + npg * H);  // [P] (self only)
 
-    const int n = blockIdx.x, tid = threadIdx.x;
+    int n = blockIdx.x;
+    if constexpr (!SELF) {
+        // workgroups b and b+8 share an XCD (and its L2): hand the rows of one image to one XCD so that
+        // only the first of them fetches the image's keys/values from beyond L2
+        const int R = a.rows_per_image, imgs = a.N / R;
+        if (R > 1 && (imgs & 7) == 0) {
+            const int xcd = n & 7, idx = n >> 3;
+            n = ((idx / R) * 8 + xcd) * R + idx % R;
+        }
+    }
+    const int tid = threadIdx.x;
     const float scale = sqrtf(1.0f / (float)hd);
     const float* qrow = a.q + (long long)n * a.ldq;
     for (int i = tid; i < H; i += 256) q_s[i] = qrow[i] * scale;
@@ -257,6 +270,179 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const AttnArgs a) {
     }
 }
 
+// Cross-attention for all rows of one image in one workgroup: the beams of an image attend to the
+// same S keys/values, so each key / value row is loaded once and used for every beam (the per-row
+// form re-reads 2*S*H elements per beam from L2, which is what bounds it).
+constexpr int MAXR = MIC_MAX_BEAM;
+
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void cross_attn_image_kernel(const AttnArgs a) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int RA = 8 / CPL, RC = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, heads = a.heads, hd = H / heads, S = a.S, R = a.rows_per_image;
+    const int C = H / VEC;
+    const int npg = 256 / C > 0 ? 256 / C : 1;
+    float* q_s = smem;                                  // [R][H]
+    float* sc = q_s + R * H;                            // [R][heads][S]
+    float* part = sc + ((R * heads * S + 3) & ~3);      // [npg][R][H]
+    const int b = blockIdx.x, tid = threadIdx.x, n0 = b * R;
+    const float scale = sqrtf(1.0f / (float)hd);
+    for (int i = tid; i < R * H; i += 256) {
+        const int j = i / H;
+        q_s[i] = a.q[(long long)(n0 + j) * a.ldq + (i - j * H)] * scale;
+    }
+    const T* kvb = (const T*)a.kv + (long long)b * S * 2 * H;
+    const int pg = tid / C, cc = tid - pg * C;
+    const bool c_active = pg < npg;
+    Vec16<T> vpre[RC];
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+        const int p = pg + i * npg;
+        if (c_active && p < S) vpre[i] = ld16(kvb + (long long)p * 2 * H + H + cc * VEC);
+    }
+    __syncthreads();
+    {   // scores: one key chunk load serves the R queries
+        const int grp = tid >> 4, gl = tid & 15;
+        const int npairs = heads * S, chunks = hd / VEC;
+        for (int pair0 = grp; pair0 < npairs; pair0 += 16 * RA) {
+            Vec16<T> kraw[RA][CPL];
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int pair = pair0 + 16 * i;
+                if (pair < npairs) {
+                    const int h = pair / S, p = pair - h * S;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int c = gl + 16 * j;
+                        if (c < chunks) kraw[i][j] = ld16(kvb + (long long)p * 2 * H + h * hd + c * VEC);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int pair = pair0 + 16 * i;
+                if (pair < npairs) {
+                    const int h = pair / S, p = pair - h * S;
+                    float sum[MAXR];
+#pragma unroll
+                    for (int rr = 0; rr < MAXR; ++rr) sum[rr] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int c = gl + 16 * j;
+                        if (c < chunks) {
+                            float kf[VEC];
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) kf[e] = to_f32<T>(kraw[i][j].v[e]);
+#pragma unroll
+                            for (int rr = 0; rr < MAXR; ++rr) {
+                                if (rr < R) {
+                                    const float* qq = q_s + rr * H + h * hd + c * VEC;
+#pragma unroll
+                                    for (int e = 0; e < VEC; ++e) sum[rr] = fmaf(qq[e], kf[e], sum[rr]);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < MAXR; ++rr) {
+                        if (rr < R) {
+                            float v = sum[rr];
+                            v += __shfl_xor(v, 8, 16);
+                            v += __shfl_xor(v, 4, 16);
+                            v += __shfl_xor(v, 2, 16);
+                            v += __shfl_xor(v, 1, 16);
+                            if (gl == 0) sc[(rr * heads + h) * S + p] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // softmax of each (row, head)
+        const int wv = tid >> 6, lane = tid & 63;
+        for (int rh = wv; rh < R * heads; rh += 4) {
+            float* row = sc + rh * S;
+            float m = -INFINITY;
+            for (int p = lane; p < S; p += 64) m = fmaxf(m, row[p]);
+            m = wave_max(m);
+            float sum = 0.f;
+            for (int p = lane; p < S; p += 64) {
+                const float e = expf(row[p] - m);
+                row[p] = e;
+                sum += e;
+            }
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+            for (int p = lane; p < S; p += 64) row[p] *= inv;
+        }
+    }
+    __syncthreads();
+    if (a.attn_out) {
+        const float hs = a.attn_scale / (float)heads;
+        for (int i = tid; i < R * S; i += 256) {
+            const int rr = i / S, p = i - rr * S;
+            float sum = 0.f;
+            for (int h = 0; h < heads; ++h) sum += sc[(rr * heads + h) * S + p];
+            float* dst = a.attn_out + (long long)(n0 + rr) * a.ld_attn + p;
+            *dst = (a.accumulate ? *dst : 0.f) + sum * hs;
+        }
+    }
+    if (c_active) {
+        const int h = (cc * VEC) / hd;
+        float acc[MAXR][VEC];
+#pragma unroll
+        for (int rr = 0; rr < MAXR; ++rr)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[rr][e] = 0.f;
+        auto use = [&](int p, const Vec16<T>& v) {
+            float vf[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) vf[e] = to_f32<T>(v.v[e]);
+#pragma unroll
+            for (int rr = 0; rr < MAXR; ++rr) {
+                if (rr < R) {
+                    const float wgt = sc[(rr * heads + h) * S + p];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[rr][e] = fmaf(wgt, vf[e], acc[rr][e]);
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const int p = pg + i * npg;
+            if (p < S) use(p, vpre[i]);
+        }
+        for (int p = pg + RC * npg; p < S; p += npg) use(p, ld16(kvb + (long long)p * 2 * H + H + cc * VEC));
+#pragma unroll
+        for (int rr = 0; rr < MAXR; ++rr) {
+            if (rr < R) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) part[(pg * R + rr) * H + cc * VEC + e] = acc[rr][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < R * H; i += 256) {
+        const int rr = i / H, col = i - rr * H;
+        float sum = 0.f;
+        for (int g = 0; g < npg; ++g) sum += part[(g * R + rr) * H + col];
+        ((T*)a.o)[(long long)(n0 + rr) * a.ld_o + col] = from_f32<T>(sum);
+    }
+}
+
+template <typename T> int launch_cross_image(const AttnArgs& a, hipStream_t s, size_t lds) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cpl = (a.H / a.heads / VEC + 15) / 16;
+    const dim3 grid(a.N / a.rows_per_image);
+    if (cpl <= 1) MIC_LAUNCH((cross_attn_image_kernel<T, 1>), grid, dim3(256), lds, s, a);
+    else if (cpl <= 2) MIC_LAUNCH((cross_attn_image_kernel<T, 2>), grid, dim3(256), lds, s, a);
+    else if (cpl <= 4) MIC_LAUNCH((cross_attn_image_kernel<T, 4>), grid, dim3(256), lds, s, a);
+    else MIC_LAUNCH((cross_attn_image_kernel<T, 8>), grid, dim3(256), lds, s, a);
+    return 0;
+}
+
 template <typename T, bool SELF> int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int VEC = Vec16<T>::N;
     const int P = SELF ? a.t + 1 : a.S;
@@ -363,6 +549,15 @@ extern "C" int mic_cross_attn_step(const float* q, int ldq, const void* kv, int 
     a.attn_out = attn_out; a.ld_attn = ld_attn; a.attn_scale = attn_scale; a.accumulate = accumulate;
     a.N = N; a.H = H; a.heads = heads;
     hipStream_t s = (hipStream_t)stream;
+    // One workgroup per image reads each key/value row once for all beams, but measured slower than
+    // one workgroup per row on MI355X (25 us vs 20 us at 768 rows, S=49, H=512): kept as an opt-in.
+    static const bool per_image = getenv("MIC_CROSS_PER_IMAGE") != nullptr;
+    if (per_image && rows_per_image > 1 && rows_per_image <= MAXR && N % rows_per_image == 0) {
+        // one workgroup per image when its beams' queries, scores and partial outputs fit in 64 KiB of LDS
+        const int vec = 16 / (int)mic_dtype_size(dtype), C = H / vec, npg = 256 / C > 0 ? 256 / C : 1, R = rows_per_image;
+        const size_t lds = sizeof(float) * ((size_t)R * H + ((R * heads * S + 3) & ~3) + (size_t)npg * R * H);
+        if (lds <= 64 * 1024) return dtype == MIC_BF16 ? launch_cross_image<bf16_t>(a, s, lds) : launch_cross_image<float>(a, s, lds);
+    }
     return dtype == MIC_BF16 ? launch_attn<bf16_t, false>(a, s) : launch_attn<float, false>(a, s);
 }
 

@@ -12,6 +12,8 @@
 // staging barrier and the two row reductions across waves.
 #include "mic_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 template <typename T> struct SkinnyMma;
@@ -205,7 +207,7 @@ __device__ __forceinline__ void merge_row_stats(const LnRef& l, int m, float& me
 
 template <typename T, int MT>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
-    constexpr int VEC = 16 / (int)sizeof(T), EPR = 4 * VEC, TPW = 2, U = 4, ROWS = MT * 16;
+    constexpr int VEC = 16 / (int)sizeof(T), EPR = 4 * VEC, TPW = 2, U = MT >= 4 ? 2 : 4, ROWS = MT * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
     __shared__ float rs_x[ROWS][2], rs_r[ROWS][2], red[2][4][ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -214,6 +216,39 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
     const int m0 = rb * ROWS, nb = cb * 128 + wave * TPW * 16;
     const int nk = a.K / EPR;
     const int xrow = a.K * (int)sizeof(T) + 16;
+    // The first 2*U k-tiles of weights (all of K up to 512 bf16 elements) are requested before the
+    // activation rows are staged: the two do not depend on each other, so the launch pays one memory
+    // round trip for both instead of two in sequence.
+    const T* wp = (const T*)a.w + ((long long)(nb / 16) * nk * 64 + lane) * VEC;
+    uint4 wa[U][TPW], wb[U][TPW];
+    auto load_w = [&](int kt0, uint4 (&wf)[U][TPW]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt0 + u < nk ? kt0 + u : nk - 1;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) wf[u][j] = *reinterpret_cast<const uint4*>(wp + ((long long)j * nk + kt) * 64 * VEC);
+        }
+    };
+    load_w(0, wa);
+    load_w(U, wb);
+    // bias, LayerNorm parameters and residual values of this lane's outputs: also requested up front
+    float bv[TPW][4], gv[TPW][4], bev[TPW][4], rv[MT][TPW][4];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int n = nb + j * 16 + q * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = n + e < a.N;
+            bv[j][e] = ok && a.bias ? a.bias[n + e] : 0.f;
+            gv[j][e] = ok && a.rl.raw ? a.rl.gamma[n + e] : 0.f;
+            bev[j][e] = ok && a.rl.raw ? a.rl.beta[n + e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = m0 + i * 16 + r, mc = m < a.M ? m : a.M - 1;
+                rv[i][j][e] = !ok ? 0.f : a.res ? a.res[(long long)mc * a.ld_res + n + e] : a.rl.raw ? a.rl.raw[(long long)mc * a.rl.ld + n + e] : 0.f;
+            }
+        }
+    }
     if (tid < ROWS) {
         const int mr = m0 + tid < a.M ? m0 + tid : a.M - 1;
         if (a.xl.raw) merge_row_stats(a.xl, mr, rs_x[tid][0], rs_x[tid][1]);
@@ -246,7 +281,6 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
         }
     }
     const unsigned char* xp = xs + r * xrow + q * 16;
-    const T* wp = (const T*)a.w + ((long long)(nb / 16) * nk * 64 + lane) * VEC;
     __syncthreads();
 
     f32x4_t acc[MT][TPW];
@@ -254,15 +288,6 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < TPW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    uint4 wa[U][TPW], wb[U][TPW];
-    auto load_w = [&](int kt0, uint4 (&wf)[U][TPW]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kt = kt0 + u < nk ? kt0 + u : nk - 1;
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) wf[u][j] = *reinterpret_cast<const uint4*>(wp + ((long long)j * nk + kt) * 64 * VEC);
-        }
-    };
     auto mma_group = [&](int kt0, const uint4 (&wf)[U][TPW]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -276,12 +301,11 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
             }
         }
     };
-    load_w(0, wa);
     for (int kt = 0; kt < nk; kt += 2 * U) {
-        load_w(kt + U, wb);
         mma_group(kt, wa);
         load_w(kt + 2 * U, wa);
         mma_group(kt + U, wb);
+        load_w(kt + 3 * U, wb);
     }
 
     // epilogue values: lane holds columns nb + j*16 + q*4 + e of rows m0 + i*16 + r
@@ -289,23 +313,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int n = nb + j * 16 + q * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f}, bev[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (n + e < a.N) {
-                if (a.bias) bv[e] = a.bias[n + e];
-                if (a.rl.raw) { gv[e] = a.rl.gamma[n + e]; bev[e] = a.rl.beta[n + e]; }
-            }
-        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int m = m0 + i * 16 + r, mc = m < a.M ? m : a.M - 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = acc[i][j][e] + bv[e];
+                float x = acc[i][j][e] + bv[j][e];
                 if (n + e < a.N) {
-                    if (a.res) x += a.res[(long long)mc * a.ld_res + n + e];
-                    if (a.rl.raw) x += (a.rl.raw[(long long)mc * a.rl.ld + n + e] - rs_r[i * 16 + r][0]) * rs_r[i * 16 + r][1] * gv[e] + bev[e];
+                    if (a.res) x += rv[i][j][e];
+                    if (a.rl.raw) x += (rv[i][j][e] - rs_r[i * 16 + r][0]) * rs_r[i * 16 + r][1] * gv[j][e] + bev[j][e];
                 } else {
                     x = 0.f;
                 }
@@ -486,9 +501,14 @@ extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) {
     a.rl = LnRef{d->res_ln.raw, d->res_ln.stats, d->res_ln.gamma, d->res_ln.beta, d->res_ln.ld, d->res_ln.parts, d->res_ln.width};
     a.ld_x = d->ld_x; a.ld_res = d->ld_res; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K; a.relu = d->relu; a.out_dtype = d->out_dtype;
     hipStream_t s = (hipStream_t)stream;
-    // two row tiles per workgroup halve the weight traffic once there are enough workgroups to fill the chip
-    const long long blocks2 = (long long)((d->N + 127) / 128) * ((d->M + 31) / 32);
-    if (blocks2 >= 512) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 2>(a, s) : launch_skinny<float, 2>(a, s);
+    // every row block re-reads its 128 weight columns from L2: 32-row blocks halve that traffic and pay
+    // off once there are still two workgroups per CU (the vocabulary projection)
+    static const int forced_mt = [] { const char* e = getenv("MIC_SKINNY_MT"); return e ? atoi(e) : 0; }();
+    const long long cbs = (d->N + 127) / 128;
+    int mt = cbs * ((d->M + 31) / 32) >= 512 ? 2 : 1;  // measured: 64-row blocks never win at these sizes
+    if (forced_mt) mt = forced_mt;
+    if (mt == 4) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 4>(a, s) : launch_skinny<float, 4>(a, s);
+    if (mt == 2) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 2>(a, s) : launch_skinny<float, 2>(a, s);
     return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 1>(a, s) : launch_skinny<float, 1>(a, s);
 }
 

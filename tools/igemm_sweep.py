@@ -95,7 +95,7 @@ def main():
         print(f"{nm:12s} M={M:8d} N={N:5d} K={K:5d} {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "ln"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("ln", "skinny")):
     main()
 
 
@@ -124,3 +124,35 @@ def fused_ln():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ln":
     fused_ln()
+
+
+def skinny():
+    dt = torch.bfloat16
+    for (M, N, K, nm) in [(768, 512, 512, "tail"), (768, 1536, 512, "qkv"), (768, 1024, 512, "ff1"), (768, 512, 1024, "ff2-tail"), (768, 3500, 512, "vocab")]:
+        x = torch.randn(M, K, device=DEV).to(dt)
+        w = amd.weights.frag_matrix(amd.weights._pad_rows(torch.randn(N, K) * 0.05), dt, DEV)
+        b = torch.randn(N, device=DEV)
+        out = torch.empty(M, N, device=DEV)
+        st = torch.zeros(M, (N + 127) // 128, 2, device=DEV)
+        res = torch.randn(M, N, device=DEV)
+        d = L.SkinnyDesc()
+        d.x, d.ld_x, d.wf, d.bias, d.out = x.data_ptr(), K, w.data_ptr(), b.data_ptr(), out.data_ptr()
+        d.dtype, d.out_dtype, d.ldc, d.M, d.N, d.K = L.BF16, L.F32, N, M, N, K
+        if "tail" in nm:
+            d.res, d.ld_res, d.stats_out = res.data_ptr(), N, st.data_ptr()
+
+        def call():
+            L.check(L.lib.mic_linear_skinny_ex(C.byref(d), L.stream_ptr()))
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"skinny {nm:9s} M={M} N={N} K={K}: {e0.elapsed_time(e1) / 100 * 1e3:.1f} us")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "skinny":
+    skinny()
