@@ -53,13 +53,25 @@ def cpu_baseline(sd, n_images: int):
                       f"recompute, fp32 torch CPU), {dt:.1f} s"}
 
 
+def measured_traffic():
+    """HBM bytes per launch of the 128-row-tile bf16 igemm kernels on this workload, from the committed
+    rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs of this script; a live
+    run cannot collect hardware counters on itself).  None when the summary file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return round(json.load(f)["igemm_bf16_128row_tiles"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
-    ap.add_argument("--cpu-images", type=int, default=12, help="sample size of the CPU baseline (0 disables it)")
+    ap.add_argument("--cpu-images", type=int, default=128, help="sample size of the CPU baseline (0 disables it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -126,12 +138,13 @@ def main():
             "config": {"workload": "configs[2]: ResNet-50 encoder + 3-layer transformer decoder (H=512, 2 heads, V=3500), beam=3, "
                                    "max_len=30, 224x224, batch 256 per GPU, bf16; random-init weights",
                        "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16,128,128>", "achieved": round(achieved, 2),
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16,128,*> (all 128-row tile variants)", "achieved": round(achieved, 2),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "traffic": None, "launches_per_step": k_n // max(1, args.steps),
+                         "traffic": measured_traffic(), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                         "launches_per_step": k_n // max(1, args.steps),
                          "avg_launch_us": round(k_ms / k_n * 1e3, 2) if k_n else None,
                          "gflop_per_launch": round(k_fl / k_n / 1e9, 3) if k_n else None,
-                         "other_gemm_launches": {"igemm<bf16,64,64>": {"n": cnt[3], "ms": round(ms[3], 3), "tflops": round(fl[3] / (ms[3] * 1e-3) / 1e12, 2) if ms[3] else None}}},
+                         "other_gemm_launches": {"igemm<bf16,64-row tiles>": {"n": cnt[3], "ms": round(ms[3], 3), "tflops": round(fl[3] / (ms[3] * 1e-3) / 1e12, 2) if ms[3] else None}}},
         }
         if args.cpu_images > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline(sd, args.cpu_images)
