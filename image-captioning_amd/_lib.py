@@ -51,6 +51,24 @@ class Resnet50(C.Structure):
     _fields_ = [("dtype", i32), ("stem", ConvLayer), ("blocks_per_stage", i32 * 4), ("conv", (ConvLayer * 4) * 16)]
 
 
+SWIN_MAX_BLOCKS = 32
+
+
+class SwinBlock(C.Structure):
+    _fields_ = [(n, vp) for n in ["qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b",
+                                  "n1_g", "n1_b", "n2_g", "n2_b", "bias_tab", "logit_scale"]]
+
+
+class SwinMerge(C.Structure):
+    _fields_ = [("w", vp), ("g", vp), ("b", vp)]
+
+
+class Swin(C.Structure):
+    _fields_ = [("dtype", i32), ("embed_dim", i32), ("depths", i32 * 4), ("heads", i32 * 4),
+                ("patch_w", vp), ("patch_b", vp), ("patch_g", vp), ("patch_be", vp),
+                ("block", SwinBlock * SWIN_MAX_BLOCKS), ("merge", SwinMerge * 3)]
+
+
 _TR_W = ["self_in_w", "self_out_w", "cross_q_w", "cross_kv_w", "cross_out_w", "ff1_w", "ff2_w"]
 _TR_B = ["self_in_b", "self_out_b", "cross_q_b", "cross_kv_b", "cross_out_b", "ff1_b", "ff2_b"]
 _TR_LN = ["ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b"]
@@ -96,6 +114,11 @@ SIGNATURES = {
     "mic_global_avgpool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_embed_pos": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_layernorm_add": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_patchify4": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_window_attn": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_swin_workspace_bytes": (C.c_int64, [P(Swin), C.c_int, C.c_int, C.c_int]),
+    "mic_swin_forward": (C.c_int, [P(Swin), vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]),
     "mic_pack_weight_frag": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mic_linear_skinny": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_linear_skinny_ex": (C.c_int, [C.POINTER(SkinnyDesc), vp]),

@@ -34,8 +34,8 @@ __global__ void embed_pos_kernel(const int32_t* __restrict__ ids, int ld_ids, in
 // ---------------------------------------------------------------------------------------------
 // one wave per row, 4 rows per block
 template <typename T>
-__global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                 float* __restrict__ y, T* __restrict__ yt, int ld_yt, int N, int H) {
+__global__ void layernorm_kernel(const float* x, const float* __restrict__ g, const float* __restrict__ b,
+                                 const float* res, float* y, T* __restrict__ yt, int ld_yt, int N, int H) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N) return;
     const float* xr = x + (long long)row * H;
@@ -60,6 +60,10 @@ __global__ void layernorm_kernel(const float* __restrict__ x, const float* __res
         o.y = (v.y - mean) * rstd * gg.y + bb.y;
         o.z = (v.z - mean) * rstd * gg.z + bb.z;
         o.w = (v.w - mean) * rstd * gg.w + bb.w;
+        if (res) {  // residual-post-norm: the normalised branch is added to the stream (res may alias y)
+            const float4 r = *reinterpret_cast<const float4*>(res + (long long)row * H + i);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
         if (y) *reinterpret_cast<float4*>(y + (long long)row * H + i) = o;
         if (yt) {
             T* t = yt + (long long)row * ld_yt + i;
@@ -519,9 +523,23 @@ extern "C" int mic_layernorm(const float* x, const float* gamma, const float* be
     MIC_ARG_CHECK(dtype == MIC_F32 || dtype == MIC_BF16, "mic_layernorm: bad dtype %d", dtype);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MIC_BF16)
-        MIC_LAUNCH(layernorm_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, y, (bf16_t*)yt, ld_yt, N, H);
+        MIC_LAUNCH(layernorm_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, (const float*)nullptr, y, (bf16_t*)yt, ld_yt, N, H);
     else
-        MIC_LAUNCH(layernorm_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, y, (float*)yt, ld_yt, N, H);
+        MIC_LAUNCH(layernorm_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, x, gamma, beta, (const float*)nullptr, y, (float*)yt, ld_yt, N, H);
+    return 0;
+}
+
+extern "C" int mic_layernorm_add(const float* u, const float* gamma, const float* beta, const float* res, float* y, void* yt,
+                                 int ld_yt, int dtype, int N, int H, void* stream) {
+    MIC_ARG_CHECK(u && gamma && beta && res && (y || yt), "mic_layernorm_add: null pointer");
+    MIC_ARG_CHECK(N > 0 && H > 0 && H % 4 == 0, "mic_layernorm_add: bad sizes N=%d H=%d", N, H);
+    MIC_ARG_CHECK(dtype == MIC_F32 || dtype == MIC_BF16, "mic_layernorm_add: bad dtype %d", dtype);
+    MIC_ARG_CHECK(u != y, "mic_layernorm_add: the branch input must not alias the output");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MIC_BF16)
+        MIC_LAUNCH(layernorm_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, u, gamma, beta, res, y, (bf16_t*)yt, ld_yt, N, H);
+    else
+        MIC_LAUNCH(layernorm_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, u, gamma, beta, res, y, (float*)yt, ld_yt, N, H);
     return 0;
 }
 

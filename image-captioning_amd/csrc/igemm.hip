@@ -249,9 +249,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                     }
                 }
             }
-            if (a.relu) {
+            if (a.relu == MIC_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (a.relu == MIC_ACT_GELU) {  // exact (erf) form, nn.GELU() default
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
             }
             const long long oo = (long long)m * a.ldc + n;
             if (a.out_dtype == MIC_F32) {
@@ -358,6 +361,7 @@ extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
     MIC_ARG_CHECK(d->dtype == MIC_F32 || d->dtype == MIC_BF16, "mic_conv2d: bad dtype %d", d->dtype);
     MIC_ARG_CHECK(d->out_dtype == MIC_F32 || d->out_dtype == MIC_BF16, "mic_conv2d: bad out_dtype %d", d->out_dtype);
     MIC_ARG_CHECK(!d->res || d->res_dtype == MIC_F32 || d->res_dtype == MIC_BF16, "mic_conv2d: bad res_dtype");
+    MIC_ARG_CHECK(d->relu >= 0 && d->relu <= MIC_ACT_GELU, "mic_conv2d: unknown activation %d", d->relu);
     MIC_ARG_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "mic_conv2d: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
     const int epr = 64 / (int)mic_dtype_size(d->dtype);
     MIC_ARG_CHECK(d->run > 0 && d->run % epr == 0, "mic_conv2d: run=%d must be a multiple of %d", d->run, epr);

@@ -16,14 +16,14 @@ import torch
 
 from . import _lib as L
 from . import weights as W
-from .encoders import ResNet50Encoder
+from .encoders import ResNet50Encoder, SwinV2Encoder
 from .vocabulary import EOS, PAD, SOS
 
 
 class ImageCaptioner:
     def __init__(self, vocab, num_heads: int = 2, dtype: torch.dtype = torch.bfloat16, encoder: str = "resnet50",
                  sync_every: int = 8, use_graph: bool = True):
-        if encoder not in ("resnet50", "none"):
+        if encoder not in ("resnet50", "swin", "none"):
             raise ValueError(f"Encoder {encoder} not recognized")
         self.vocab = vocab
         self.num_heads = num_heads
@@ -48,10 +48,20 @@ class ImageCaptioner:
         if self.encoder_kind == "resnet50" and "encoder.resnet.0.weight" not in state_dict:
             raise KeyError("state dict has no ResNet-50 encoder (encoder.resnet.*); construct with encoder='none' "
                            "to decode from precomputed features")
+        if self.encoder_kind == "swin" and self._swin_prefix(state_dict) is None:
+            raise KeyError("state dict has no Swin encoder (encoder.features.* / encoder.swin.features.*)")
         self._sd = {k: v.detach().cpu() for k, v in state_dict.items()}
         self.max_len = self._sd["seq_embedding.pos_embedding.weight"].shape[0]
         self.device = None
         return self
+
+    @staticmethod
+    def _swin_prefix(sd):
+        """models/encoders/swin.py:26,29 registers the trunk twice; either name serves."""
+        for p in ("encoder.features.", "encoder.swin.features."):
+            if p + "0.0.weight" in sd:
+                return p
+        return None
 
     def to(self, device):
         device = torch.device(device)
@@ -63,7 +73,12 @@ class ImageCaptioner:
             return self
         with torch.cuda.device(device):
             self.dec, self._dec_keep = W.build_tr_decoder(self._sd, self.num_heads, self.dtype, device)
-            self.encoder = ResNet50Encoder(self._sd, "transformer", self.dtype, device) if self.encoder_kind == "resnet50" else None
+            if self.encoder_kind == "resnet50":
+                self.encoder = ResNet50Encoder(self._sd, "transformer", self.dtype, device)
+            elif self.encoder_kind == "swin":
+                self.encoder = SwinV2Encoder(self._sd, self.dtype, device, self._swin_prefix(self._sd))
+            else:
+                self.encoder = None
         self.device = device
         self._ws_cache = {}
         return self
@@ -251,5 +266,6 @@ class ImageCaptioner:
     def from_state_dict(cls, state_dict, vocab, num_heads: int = 2, dtype=torch.bfloat16, device="cuda",
                         encoder: Optional[str] = None, **kw) -> "ImageCaptioner":
         if encoder is None:
-            encoder = "resnet50" if "encoder.resnet.0.weight" in state_dict else "none"
+            encoder = ("resnet50" if "encoder.resnet.0.weight" in state_dict
+                       else "swin" if cls._swin_prefix(state_dict) else "none")
         return cls(vocab, num_heads, dtype, encoder, **kw).load_state_dict(state_dict).to(device)

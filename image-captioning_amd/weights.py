@@ -129,6 +129,97 @@ def build_resnet50(sd: SD, prefix: str, dtype: torch.dtype, device) -> tuple:
     return net, keep
 
 
+def swin_relative_tables(window: int = 8):
+    """The two buffers of torchvision's ShiftedWindowAttentionV2: log-spaced relative coordinates
+    (1, 2w-1, 2w-1, 2) and the (w^2 * w^2) index of each token pair into that table."""
+    r = torch.arange(-(window - 1), window, dtype=torch.float32)
+    table = torch.stack(torch.meshgrid([r, r], indexing="ij")).permute(1, 2, 0).contiguous().unsqueeze(0)
+    table = table / (window - 1) * 8
+    table = torch.sign(table) * torch.log2(torch.abs(table) + 1.0) / 3.0
+    c = torch.arange(window)
+    coords = torch.stack(torch.meshgrid(c, c, indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += window - 1
+    rel[:, :, 1] += window - 1
+    rel[:, :, 0] *= 2 * window - 1
+    return table, rel.sum(-1).flatten()
+
+
+def swin_config_of(sd: SD, prefix: str = "encoder.features."):
+    """(embed_dim, depths, heads) read off the parameter shapes."""
+    embed = sd[prefix + "0.0.weight"].shape[0]
+    depths, heads = [], []
+    for si in range(4):
+        d = 0
+        while f"{prefix}{1 + 2 * si}.{d}.attn.qkv.weight" in sd:
+            d += 1
+        if d == 0:
+            raise KeyError(f"state dict has no Swin stage {si} under {prefix}{1 + 2 * si}.*")
+        depths.append(d)
+        heads.append(int(sd[f"{prefix}{1 + 2 * si}.0.attn.logit_scale"].shape[0]))
+    return embed, depths, heads
+
+
+def build_swin(sd: SD, prefix: str, dtype: torch.dtype, device, window: int = 8) -> tuple:
+    """torchvision swin_v2_* ``features`` parameters under ``prefix`` ('encoder.features.') -> mic_swin.
+    Input-independent pieces are evaluated here once: the continuous position bias
+    16*sigmoid(cpb_mlp(table))[index] per head, exp(min(logit_scale, log 100)), and the zeroed key bias."""
+    keep = Keep()
+    net = L.Swin()
+    embed, depths, heads = swin_config_of(sd, prefix)
+    if sum(depths) > L.SWIN_MAX_BLOCKS:
+        raise ValueError(f"{sum(depths)} Swin blocks exceed the supported {L.SWIN_MAX_BLOCKS}")
+    if embed % 32:
+        raise ValueError(f"Swin embed_dim {embed} must be a multiple of 32")
+    net.dtype, net.embed_dim = L.dtype_code(dtype), embed
+    pw = sd[prefix + "0.0.weight"]
+    if tuple(pw.shape[1:]) != (3, 4, 4):
+        raise ValueError(f"patch embedding must be a 4x4 convolution over 3 channels, got {tuple(pw.shape)}")
+    pm = torch.zeros(embed, 4, 4, 4)
+    pm[:, :, :, :3] = pw.permute(0, 2, 3, 1).float()
+    net.patch_w = keep(matrix(pm.reshape(embed, 64), dtype, device))
+    net.patch_b = keep(vector(sd[prefix + "0.0.bias"], device))
+    net.patch_g = keep(vector(sd[prefix + "0.2.weight"], device))
+    net.patch_be = keep(vector(sd[prefix + "0.2.bias"], device))
+    table0, index0 = swin_relative_tables(window)
+    n = window * window
+    bi = 0
+    for si in range(4):
+        C_ = embed << si
+        net.depths[si], net.heads[si] = depths[si], heads[si]
+        if heads[si] * 32 != C_:
+            raise ValueError(f"Swin stage {si}: {heads[si]} heads over {C_} channels is not 32 channels per head")
+        for k in range(depths[si]):
+            p = f"{prefix}{1 + 2 * si}.{k}."
+            B_ = net.block[bi]
+            qb = sd[p + "attn.qkv.bias"].detach().float().clone()
+            qb[C_:2 * C_] = 0  # the key bias is held at zero (ShiftedWindowAttentionV2)
+            B_.qkv_w, B_.qkv_b = keep(matrix(sd[p + "attn.qkv.weight"], dtype, device)), keep(vector(qb, device))
+            B_.proj_w, B_.proj_b = keep(matrix(sd[p + "attn.proj.weight"], dtype, device)), keep(vector(sd[p + "attn.proj.bias"], device))
+            B_.fc1_w, B_.fc1_b = keep(matrix(sd[p + "mlp.0.weight"], dtype, device)), keep(vector(sd[p + "mlp.0.bias"], device))
+            B_.fc2_w, B_.fc2_b = keep(matrix(sd[p + "mlp.3.weight"], dtype, device)), keep(vector(sd[p + "mlp.3.bias"], device))
+            for j in (1, 2):
+                setattr(B_, f"n{j}_g", keep(vector(sd[p + f"norm{j}.weight"], device)))
+                setattr(B_, f"n{j}_b", keep(vector(sd[p + f"norm{j}.bias"], device)))
+            table = sd.get(p + "attn.relative_coords_table", table0).float()
+            index = sd.get(p + "attn.relative_position_index", index0).long()
+            t = torch.relu(table @ sd[p + "attn.cpb_mlp.0.weight"].float().T + sd[p + "attn.cpb_mlp.0.bias"].float())
+            t = (t @ sd[p + "attn.cpb_mlp.2.weight"].float().T).view(-1, heads[si])
+            bias = 16 * torch.sigmoid(t[index].view(n, n, heads[si]).permute(2, 0, 1))
+            B_.bias_tab = keep(vector(bias, device))
+            ls = torch.clamp(sd[p + "attn.logit_scale"].detach().float().view(-1), max=math.log(100.0)).exp()
+            B_.logit_scale = keep(vector(ls, device))
+            bi += 1
+        if si < 3:
+            p = f"{prefix}{2 + 2 * si}."
+            w = sd[p + "reduction.weight"].float()  # columns: [x(0,0) | x(1,0) | x(0,1) | x(1,1)] by (row, col) parity
+            w = w.view(2 * C_, 4, C_)[:, [0, 2, 1, 3], :].reshape(2 * C_, 4 * C_)  # -> (kh, kw) raster order
+            net.merge[si].w = keep(matrix(w, dtype, device))
+            net.merge[si].g = keep(vector(sd[p + "norm.weight"], device))
+            net.merge[si].b = keep(vector(sd[p + "norm.bias"], device))
+    return net, keep
+
+
 def build_tr_decoder(sd: SD, heads: int, dtype: torch.dtype, device) -> tuple:
     """models/transformer.py parameter names -> mic_tr_decoder."""
     keep = Keep()
@@ -241,6 +332,47 @@ def random_resnet50_state(seed: int = 0, prefix: str = "encoder.resnet.") -> SD:
     return sd
 
 
+def random_swin_state(seed: int = 0, embed: int = 96, depths=(2, 2, 18, 2), heads=(3, 6, 12, 24), window: int = 8,
+                      prefix: str = "encoder.features.") -> SD:
+    """Random Swin-V2 parameters under the names models/encoders/swin.py:29 registers (defaults: the S configuration)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def lin(name, o, i, bias=True, std=0.02):
+        sd[name + ".weight"] = torch.randn(o, i, generator=g) * std
+        if bias:
+            sd[name + ".bias"] = 0.02 * torch.randn(o, generator=g)
+
+    def ln(name, c):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+
+    sd[prefix + "0.0.weight"] = torch.randn(embed, 3, 4, 4, generator=g) * 0.1
+    sd[prefix + "0.0.bias"] = 0.02 * torch.randn(embed, generator=g)
+    ln(prefix + "0.2", embed)
+    table, index = swin_relative_tables(window)
+    for si in range(4):
+        C_ = embed * 2 ** si
+        for k in range(depths[si]):
+            p = f"{prefix}{1 + 2 * si}.{k}."
+            lin(p + "attn.qkv", 3 * C_, C_, std=0.05)
+            lin(p + "attn.proj", C_, C_, std=0.05)
+            sd[p + "attn.logit_scale"] = torch.log(10 * torch.ones(heads[si], 1, 1)) + 0.3 * torch.randn(heads[si], 1, 1, generator=g)
+            lin(p + "attn.cpb_mlp.0", 512, 2, std=0.5)
+            lin(p + "attn.cpb_mlp.2", heads[si], 512, bias=False, std=0.1)
+            sd[p + "attn.relative_coords_table"] = table.clone()
+            sd[p + "attn.relative_position_index"] = index.clone()
+            ln(p + "norm1", C_)
+            ln(p + "norm2", C_)
+            lin(p + "mlp.0", 4 * C_, C_, std=0.05)
+            lin(p + "mlp.3", C_, 4 * C_, std=0.05)
+        if si < 3:
+            p = f"{prefix}{2 + 2 * si}."
+            lin(p + "reduction", 2 * C_, 4 * C_, bias=False, std=0.05)
+            ln(p + "norm", 2 * C_)
+    return sd
+
+
 def output_bias_from_counts(counts: Sequence[float], banned=(0, 1, 3)) -> torch.Tensor:
     """Log-unigram output bias with PAD/SOS/UNK at -1e9 (Output.adapt, models/transformer.py:248-284)."""
     c = torch.tensor([0.0 if i in banned else float(x) for i, x in enumerate(counts)], dtype=torch.float64)
@@ -305,11 +437,11 @@ def random_lstm_state(kind: str, V: int, E: int, Hd: int, layers: int, seed: int
     return sd
 
 
-def random_head_state(kind: str, out_dim: int, seed: int = 0) -> SD:
-    """Encoder head under the reference's names: projection.0 (transformer), linear.0 (intermediate), linear (basic)."""
+def random_head_state(kind: str, out_dim: int, seed: int = 0, in_dim: int = 2048) -> SD:
+    """Encoder head under the reference's names: projection.0 (transformer / swin), linear.0 (intermediate), linear (basic)."""
     g = torch.Generator().manual_seed(seed + 17)
-    b = 1 / math.sqrt(2048)
-    if kind == "transformer":
-        return {"encoder.projection.0.weight": _uniform(g, (out_dim, 2048, 1, 1), b), "encoder.projection.0.bias": _uniform(g, (out_dim,), b)}
+    b = 1 / math.sqrt(in_dim)
+    if kind in ("transformer", "swin"):
+        return {"encoder.projection.0.weight": _uniform(g, (out_dim, in_dim, 1, 1), b), "encoder.projection.0.bias": _uniform(g, (out_dim,), b)}
     name = "encoder.linear.0" if kind == "intermediate" else "encoder.linear"
-    return {name + ".weight": _uniform(g, (out_dim, 2048), b), name + ".bias": _uniform(g, (out_dim,), b)}
+    return {name + ".weight": _uniform(g, (out_dim, in_dim), b), name + ".bias": _uniform(g, (out_dim,), b)}

@@ -30,6 +30,11 @@ extern "C" {
 #define MIC_BF16 1
 #define MIC_ERR_ARG (-1)
 
+/* activation codes of the GEMM epilogues (the `relu` field / argument) */
+#define MIC_ACT_NONE 0
+#define MIC_ACT_RELU 1
+#define MIC_ACT_GELU 2      /* x/2 * (1 + erf(x / sqrt 2)); mic_conv2d only */
+
 #define MIC_MAX_BEAM 8      /* beam width accepted by the search kernels */
 #define MIC_MAX_LAYERS 8    /* decoder depth accepted by the step drivers (sweeper/config.py:80 tops out at 6) */
 
@@ -67,7 +72,7 @@ typedef struct mic_conv_desc {
     int32_t kw_taps, run;
     int32_t stride, pad_h, pad_w;
     int32_t ldc, ld_res;
-    int32_t relu;
+    int32_t relu;         /* MIC_ACT_* */
     int32_t k_valid;      /* k entries that are not structural zero padding (0 = K); only used for FLOP accounting */
 } mic_conv_desc;
 int mic_conv2d(const mic_conv_desc* d, void* stream);
@@ -95,6 +100,25 @@ int mic_maxpool3x3s2(const void* in, void* out, int dtype, int B, int H, int W, 
  * ld_out is the row stride of out in elements. */
 int mic_global_avgpool(const void* in, void* out, int dtype, int B, int HW, int C, int ld_out, void* stream);
 
+/* (B,3,H,W) fp32 planar image -> non-overlapping 4x4 patches [B][H/4][W/4][64] of `dtype`,
+ * element (kh*4 + kw)*4 + c with a zero 4th channel: the im2col of the 4x4/4 patch-embedding
+ * convolution (torchvision swin features[0][0], models/encoders/swin.py:26,68), which then is a
+ * plain K=64 GEMM through mic_conv2d. */
+int mic_patchify4(const float* images, void* out, int dtype, int B, int H, int W, void* stream);
+
+/* Shifted-window cosine attention of Swin-V2 for every (image, 8x8 window, head):
+ *   o = softmax( normalize(q) normalize(k)^T * logit_scale[h] + bias_tab[h] + shift_mask ) v
+ * (torchvision shifted_window_attention with logit_scale, between the qkv and proj linears;
+ * models/encoders/swin.py:68).  qkv [B*H*W][3C] of `dtype` is the packed projection of the
+ * UNPADDED, UNSHIFTED token map; zero padding of H, W to multiples of 8, the cyclic shift by
+ * `shift` (dropped on an axis one window covers), window partition and their inverses are index
+ * arithmetic inside the kernel.  Padded slots take qkv_bias (fp32 [3C], key third zero) as their
+ * projection.  bias_tab fp32 [heads][64][64] = 16*sigmoid(cpb_mlp(table))[index]; logit_scale fp32
+ * [heads] = exp(min(param, log 100)); both precomputed by the host at load time.  C = heads*32.
+ * o [B*H*W][C] of `dtype` (input of the proj GEMM). */
+int mic_window_attn(const void* qkv, const float* qkv_bias, const float* bias_tab, const float* logit_scale, void* o,
+                    int dtype, int B, int H, int W, int C, int heads, int shift, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Decoder step building blocks
  * ---------------------------------------------------------------------------------------- */
@@ -111,6 +135,12 @@ int mic_embed_pos(const int32_t* ids, int ld_ids, int pos, const float* tok_emb,
  * models/intermediate.py:64. */
 int mic_layernorm(const float* x, const float* gamma, const float* beta, float* y, void* yt, int ld_yt,
                   int dtype, int N, int H, void* stream);
+
+/* Residual-post-norm update y = res + LN(u) * gamma + beta (eps 1e-5): the block form of Swin-V2,
+ * x = x + norm(attn(x)) / x = x + norm(mlp(x)) (torchvision SwinTransformerBlockV2.forward, reached
+ * from models/encoders/swin.py:68).  y may alias res; u must not alias y.  Optional `dtype` copy yt. */
+int mic_layernorm_add(const float* u, const float* gamma, const float* beta, const float* res, float* y, void* yt,
+                      int ld_yt, int dtype, int N, int H, void* stream);
 
 /* Fused tail of a post-LN transformer sub-layer in one launch:
  *   y = LayerNorm(x W^T + bias + res) * gamma + beta,   eps 1e-5
@@ -273,6 +303,39 @@ int64_t mic_resnet50_workspace_bytes(const mic_resnet50* net, int B, int H, int 
  * torchvision resnet50 children[:-2] as used by models/encoders/transformer.py:24-28,46. */
 int mic_resnet50_forward(const mic_resnet50* net, const float* images, int B, int H, int W,
                          void* workspace, int64_t workspace_bytes, void* out, void* stream);
+
+/* Swin-V2 feature extractor (torchvision swin_v2_{t,s,b}.features as used by
+ * models/encoders/swin.py:26-30,68): 4x4 patch embedding + LayerNorm, four stages of
+ * residual-post-norm blocks with 8x8 (shifted) window cosine attention and a GELU MLP, 2x2 patch
+ * merging (reduction + LayerNorm) between stages, no final norm. */
+#define MIC_SWIN_MAX_BLOCKS 32
+typedef struct mic_swin_block {
+    const void *qkv_w, *proj_w, *fc1_w, *fc2_w;          /* dtype, rows padded to 128 */
+    const float *qkv_b, *proj_b, *fc1_b, *fc2_b;         /* qkv_b: key third zero */
+    const float *n1_g, *n1_b, *n2_g, *n2_b;
+    const float* bias_tab;                               /* [heads][64][64] */
+    const float* logit_scale;                            /* [heads] */
+} mic_swin_block;
+
+typedef struct mic_swin_merge {
+    const void* w;        /* dtype [2C padded][4C], input blocks ordered (kh,kw) = (0,0),(0,1),(1,0),(1,1) */
+    const float *g, *b;   /* LayerNorm over 2C */
+} mic_swin_merge;
+
+typedef struct mic_swin {
+    int32_t dtype, embed_dim;
+    int32_t depths[4], heads[4];                         /* heads[s] * 32 == embed_dim << s */
+    const void* patch_w;                                 /* dtype [embed padded][64], k = (kh*4+kw)*4+c */
+    const float *patch_b, *patch_g, *patch_be;           /* conv bias, LayerNorm weight / bias */
+    mic_swin_block block[MIC_SWIN_MAX_BLOCKS];           /* stage-major */
+    mic_swin_merge merge[3];
+} mic_swin;
+
+int64_t mic_swin_workspace_bytes(const mic_swin* net, int B, int H, int W);
+/* images fp32 (B,3,H,W) -> out [B][ceil(H/32)*ceil(W/32)][8*embed_dim] in net->dtype (channels-last
+ * tokens; H and W multiples of 4). */
+int mic_swin_forward(const mic_swin* net, const float* images, int B, int H, int W, void* workspace,
+                     int64_t workspace_bytes, void* out, void* stream);
 
 typedef struct mic_tr_layer {
     const void *self_in_w, *self_out_w, *cross_q_w, *cross_kv_w, *cross_out_w, *ff1_w, *ff2_w; /* dtype, padded */

@@ -40,9 +40,10 @@ def test_struct_layouts_match_the_header():
     #include <stddef.h>
     #include "mic_hip.h"
     int main(void) {
-      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mic_conv_desc), sizeof(mic_beam_state), sizeof(mic_conv_layer),
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mic_conv_desc), sizeof(mic_beam_state), sizeof(mic_conv_layer),
              sizeof(mic_resnet50), sizeof(mic_tr_layer), sizeof(mic_tr_decoder), sizeof(mic_tr_workspace),
-             sizeof(mic_lstm_decoder), sizeof(mic_lstm_workspace), sizeof(mic_ln_ref), sizeof(mic_skinny_desc));
+             sizeof(mic_lstm_decoder), sizeof(mic_lstm_workspace), sizeof(mic_ln_ref), sizeof(mic_skinny_desc),
+             sizeof(mic_swin_block), sizeof(mic_swin_merge), sizeof(mic_swin));
       printf("%zu %zu %zu %zu\n", offsetof(mic_conv_desc, in_img_stride), offsetof(mic_conv_desc, k_valid),
              offsetof(mic_tr_decoder, out_w), offsetof(mic_lstm_decoder, out_k));
       return 0;
@@ -55,7 +56,7 @@ def test_struct_layouts_match_the_header():
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         sizes, offs = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().split("\n")
     got = [C.sizeof(x) for x in (L.ConvDesc, L.BeamState, L.ConvLayer, L.Resnet50, L.TrLayer, L.TrDecoder, L.TrWorkspace,
-                                 L.LstmDecoder, L.LstmWorkspace, L.LnRef, L.SkinnyDesc)]
+                                 L.LstmDecoder, L.LstmWorkspace, L.LnRef, L.SkinnyDesc, L.SwinBlock, L.SwinMerge, L.Swin)]
     assert got == [int(v) for v in sizes.split()]
     assert [L.ConvDesc.in_img_stride.offset, L.ConvDesc.k_valid.offset, L.TrDecoder.out_w.offset, L.LstmDecoder.out_k.offset] == \
         [int(v) for v in offs.split()]
@@ -77,6 +78,16 @@ def test_argument_errors_need_no_gpu():
     net.dtype = L.BF16
     b256 = L.lib.mic_resnet50_workspace_bytes(C.byref(net), 256, 224, 224)
     assert 1_700_000_000 < b256 < 1_800_000_000  # packed image + 3 x (256*112*112*64) + 2 x (256*56*56*128) bf16
+    sw = L.Swin()
+    sw.dtype, sw.embed_dim = L.BF16, 96
+    for i, (dp, hd) in enumerate(zip((2, 2, 18, 2), (3, 6, 12, 24))):
+        sw.depths[i], sw.heads[i] = dp, hd
+    per_token = 96 * (4 + 2 + 6 + 2 + 4 + 8)  # x, xt, qkv, o, u, hidden bytes per stage-0 token
+    assert L.lib.mic_swin_workspace_bytes(C.byref(sw), 8, 224, 224) == 8 * 56 * 56 * per_token
+    sw.heads[2] = 8
+    assert L.lib.mic_swin_workspace_bytes(C.byref(sw), 8, 224, 224) == -1  # 384 channels need 12 heads of 32
+    assert L.lib.mic_window_attn(None, None, None, None, None, 0, 1, 8, 8, 32, 1, 0, None) == -1
+    assert L.lib.mic_patchify4(None, None, 0, 1, 8, 8, None) == -1
     with pytest.raises(L.MicError, match="argument error"):
         L.check(-1, "probe")
 
