@@ -27,15 +27,35 @@ V, H, LAYERS, HEADS, POS_ROWS = 3500, 512, 3, 2, 40
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X
 
 
-def build_state():
+# secondary workloads (parity-test configurations of the same path; the default is the headline one)
+WORKLOADS = {
+    "transformer": dict(batch=256, beam=3, label="configs[2]: ResNet-50 encoder + 3-layer transformer decoder (H=512, 2 heads, V=3500), "
+                        "beam=3, max_len=30, 224x224, batch 256 per GPU, bf16; random-init weights"),
+    "swin": dict(batch=512, beam=5, label="configs[3]: Swin-V2-S encoder + 3-layer transformer decoder (H=512, 2 heads, V=3500), beam=5, "
+                 "max_len=30, 224x224, batch 512 per GPU, bf16; random-init weights"),
+    "lstm": dict(batch=64, beam=3, label="configs[1]: ResNet-50 encoder + 2-layer LSTM decoder (intermediate model, E=H=512, V=3500), "
+                 "beam=3, max_len=30, 224x224, batch 64 per GPU, bf16; random-init weights"),
+}
+
+
+def build_state(workload: str = "transformer"):
     import image_captioning_amd as amd
-    sd = amd.weights.random_resnet50_state(0)
-    sd.update(amd.weights.random_head_state("transformer", H, 0))
+    if workload == "swin":
+        sd = amd.weights.random_swin_state(0)
+        sd.update(amd.weights.random_head_state("swin", H, 0, in_dim=768))
+    elif workload == "lstm":
+        sd = amd.weights.random_resnet50_state(0)
+        sd.update(amd.weights.random_head_state("intermediate", H, 0))
+        sd.update(amd.weights.random_lstm_state("intermediate", V, H, H, 2, seed=0))
+        return sd
+    else:
+        sd = amd.weights.random_resnet50_state(0)
+        sd.update(amd.weights.random_head_state("transformer", H, 0))
     sd.update(amd.weights.random_transformer_state(V, H, LAYERS, POS_ROWS, seed=0))
     return sd
 
 
-def cpu_baseline(sd, n_images: int):
+def cpu_baseline(sd, n_images: int, workload: str, beam: int):
     """The oracle (reference-as-written search, fp32 PyTorch-CPU) on the first images of the same
     synthetic workload, timed on this host's cores."""
     import torch
@@ -45,11 +65,14 @@ def cpu_baseline(sd, n_images: int):
     img = torch.randn(n_images, 3, IMG, IMG, generator=torch.Generator().manual_seed(1234))
     t0 = time.perf_counter()
     with torch.no_grad():
-        feats = O.encoder_transformer(sd, img)
-        O.transformer_generate(sd, HEADS, feats, MAX_LEN, None, BEAM)
+        if workload == "lstm":
+            O.lstm_generate(sd, "intermediate", O.encoder_intermediate(sd, img), MAX_LEN, None, beam)
+        else:
+            feats = (O.encoder_swin if workload == "swin" else O.encoder_transformer)(sd, img)
+            O.transformer_generate(sd, HEADS, feats, MAX_LEN, None, beam)
     dt = time.perf_counter() - t0
     return {"value": round(n_images / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n_images} images of the same workload (ResNet-50 + per-image beam={BEAM} search with full-prefix "
+            "sample": f"{n_images} images of the same workload (encoder + per-image beam={beam} search with full-prefix "
                       f"recompute, fp32 torch CPU), {dt:.1f} s"}
 
 
@@ -70,7 +93,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="transformer")
     ap.add_argument("--cpu-images", type=int, default=128, help="sample size of the CPU baseline (0 disables it)")
     args = ap.parse_args()
 
@@ -91,16 +115,26 @@ def main():
     torch.cuda.set_device(dev)
     L = amd._lib
 
-    sd = build_state()
+    wl = WORKLOADS[args.workload]
+    beam = wl["beam"]
+    sd = build_state(args.workload)
     vocab = amd.Vocabulary.synthetic(V)
-    model = amd.transformer.ImageCaptioner(vocab, HEADS, torch.bfloat16, sync_every=MAX_LEN).load_state_dict(sd).to(dev)
-    B = args.batch
+    if args.workload == "lstm":
+        model = amd.lstm.IntermediateImageCaptioner(vocab, torch.bfloat16, sync_every=MAX_LEN).load_state_dict(sd).to(dev)
+    else:
+        model = amd.transformer.ImageCaptioner(vocab, HEADS, torch.bfloat16, encoder="swin" if args.workload == "swin" else "resnet50",
+                                               sync_every=MAX_LEN).load_state_dict(sd).to(dev)
+    B = args.batch or wl["batch"]
     images = torch.randn(B, 3, IMG, IMG, generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev)
     n_total = B * world
 
     def step():
-        feats = model.encode(images)
-        tokens, lengths, score, _ = model.beam_search_ids(feats, MAX_LEN, BEAM)
+        feats = model.encoder(images) if args.workload == "lstm" else model.encode(images)
+        if args.workload == "lstm":
+            tokens, lengths = model.beam_search_ids(feats, MAX_LEN, beam)
+            score = torch.zeros(B, device=dev)  # models/image_captioner.py:61-69 returns no scores
+        else:
+            tokens, lengths, score, _ = model.beam_search_ids(feats, MAX_LEN, beam)
         return D.gather_captions(tokens, lengths, score, n_total)
 
     def fence():
@@ -131,23 +165,22 @@ def main():
         k_ms, k_n, k_fl = ms[1], cnt[1], fl[1]
         achieved = (k_fl / k_n) / (k_ms / k_n * 1e-3) / 1e12 if k_n else 0.0
         res = {
-            "metric": "images captioned/sec (224^2, beam=3, max_len=30)", "value": round(n_total * args.steps / elapsed, 2),
+            "metric": f"images captioned/sec (224^2, beam={beam}, max_len=30)", "value": round(n_total * args.steps / elapsed, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[2]: ResNet-50 encoder + 3-layer transformer decoder (H=512, 2 heads, V=3500), beam=3, "
-                                   "max_len=30, 224x224, batch 256 per GPU, bf16; random-init weights",
+            "config": {"workload": wl["label"] if B == wl["batch"] else wl["label"].replace(f"batch {wl['batch']}", f"batch {B}"),
                        "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16,128,*> (all 128-row tile variants)", "achieved": round(achieved, 2),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "traffic": measured_traffic(), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                         "traffic": measured_traffic() if args.workload == "transformer" and B == BATCH else None, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                          "launches_per_step": k_n // max(1, args.steps),
                          "avg_launch_us": round(k_ms / k_n * 1e3, 2) if k_n else None,
                          "gflop_per_launch": round(k_fl / k_n / 1e9, 3) if k_n else None,
                          "other_gemm_launches": {"igemm<bf16,64-row tiles>": {"n": cnt[3], "ms": round(ms[3], 3), "tflops": round(fl[3] / (ms[3] * 1e-3) / 1e12, 2) if ms[3] else None}}},
         }
         if args.cpu_images > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(sd, args.cpu_images)
+            res["cpu_baseline"] = cpu_baseline(sd, args.cpu_images, args.workload, beam)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
