@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
+    ap.add_argument("--decode-groups", type=int, default=1, help="concurrent beam-search sub-batches per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="transformer")
     ap.add_argument("--cpu-images", type=int, default=128, help="sample size of the CPU baseline (0 disables it)")
     args = ap.parse_args()
@@ -123,7 +124,7 @@ def main():
         model = amd.lstm.IntermediateImageCaptioner(vocab, torch.bfloat16, sync_every=MAX_LEN).load_state_dict(sd).to(dev)
     else:
         model = amd.transformer.ImageCaptioner(vocab, HEADS, torch.bfloat16, encoder="swin" if args.workload == "swin" else "resnet50",
-                                               sync_every=MAX_LEN).load_state_dict(sd).to(dev)
+                                               sync_every=MAX_LEN, decode_groups=args.decode_groups).load_state_dict(sd).to(dev)
     B = args.batch or wl["batch"]
     images = torch.randn(B, 3, IMG, IMG, generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev)
     n_total = B * world
@@ -171,7 +172,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl["label"] if B == wl["batch"] else wl["label"].replace(f"batch {wl['batch']}", f"batch {B}"),
                        "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16,128,*> (all 128-row tile variants)", "achieved": round(achieved, 2),
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16> (all tile variants of 128 rows and more)", "achieved": round(achieved, 2),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                          "traffic": measured_traffic() if args.workload == "transformer" and B == BATCH else None, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                          "launches_per_step": k_n // max(1, args.steps),

@@ -56,24 +56,63 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, int KT>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+// RES_PRE: the bf16 residual tile is requested before the main loop and held in registers, so its HBM
+// latency hides behind the loads and MFMAs instead of sitting in the epilogue (the 1x1 expansion
+// convolutions have K as small as 64: their time is the residual read and the output write).
+//
+// GLDS: operand tiles go global -> LDS directly (global_load_lds_dwordx4, no register staging and no
+// ds_write pass).  One wave-instruction fills 1 KiB = 16 rows of one 64-byte sub-tile in lane order;
+// the XOR swizzle of the LDS image is applied to the SOURCE chunk each lane fetches.  Rows outside the
+// problem, taps outside the image and the K tail fetch a 16-byte block of zeros instead.
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One global_load_lds_dwordx4: every lane fetches 16 bytes from its own global address, the wave's
+// 1 KiB lands at LDS address `lds_base` + 16 * lane.  Issued from inline assembly on purpose: the
+// compiler tracks a direct-to-LDS load it can see as a pending LDS write and drains the vector-memory
+// counter (vmcnt(0)) before the next LDS read, which would serialise the multi-stage pipeline.  Ordering
+// is explicit instead: counted s_waitcnt vmcnt + s_barrier before a stage is read.  M0 (the LDS base
+// register) belongs to the compiler, so it is saved and restored around the instruction.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+
+// With GLDS the LDS holds NS stages and NS-1 tiles are kept in flight: a wave waits (counted vmcnt)
+// only for its own pieces of the tile about to be consumed, one barrier publishes the tile and frees
+// the buffer consumed in the previous step, which is refilled at once.  Tiles past the end of K are
+// requested as zeros so the wait count is the same in every iteration.
+//
+// A workgroup is WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile.  Operand bytes fetched per
+// FLOP fall as (BM + BN) / (BM * BN): the kernel is bound by the per-CU fill rate (L2 -> LDS) well
+// before the MFMA rate, so the large-M layers take 256-row tiles with 8 waves.
+template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs a) {
+    constexpr int NW = WM * WN, NT = 64 * NW;  // waves, threads
+    constexpr int RW = BM / WM, CW = BN / WN;  // rows / columns per wave
     constexpr int VEC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
     constexpr int EPR = 4 * VEC;              // K elements per 64-byte sub-tile row
     constexpr int R4 = 4 * KT;                // 16-byte chunks per row per stage
-    constexpr int RSTEP = 256 / R4;           // rows covered by one pass of the 256 threads
+    constexpr int RSTEP = NT / R4;            // rows covered by one pass of the workgroup's threads
     constexpr int XC = BM / RSTEP, WC = BN / RSTEP;
-    constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 MFMA tiles per wave along m / n
+    constexpr int TM = RW / 16, TN = CW / 16;  // 16x16 MFMA tiles per wave along m / n
+    static_assert(BM % RSTEP == 0 && BN % RSTEP == 0 && RW % 16 == 0 && CW % 16 == 0, "tile / workgroup shape");
     constexpr int STAGE = KT * (BM + BN) * 64;  // bytes of one stage: KT sub-tiles of X then of W
     // epilogue staging: fp32 accumulators of PASS_ROWS rows, padded rows (conflict-light b128 writes)
-    constexpr int PASS_ROWS = BM == 128 ? 64 : BM;
+    // (one wave-row of the workgroup at a time when a wave owns 64 rows, else the whole tile at once)
+    constexpr int PASS_ROWS = RW >= 64 ? RW : BM;
     constexpr int LDC_S = BN + 4;
     constexpr int EPI = PASS_ROWS * LDC_S * 4;
-    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    constexpr int SMEM = NS * STAGE > EPI ? NS * STAGE : EPI;
+    static_assert(GLDS || NS == 2, "register staging is double-buffered");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // Blocks b and b+8 share an XCD (and its L2): give each XCD a contiguous range of tiles so that
     // the n-tiles reading the same activation rows hit one L2.
@@ -104,6 +143,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         x_w[i] = ow * a.stride - a.pad_w;
     }
     const T* w_src = w + (long long)(n0 + row0) * a.K + kt_own * EPR + q_own * VEC;
+    // weight matrices are padded to a multiple of 128 rows: tiles wider than that must not read past it
+    const int n_rows = (a.N + 127) & ~127;
+    bool w_ok[WC];
+#pragma unroll
+    for (int i = 0; i < WC; ++i) w_ok[i] = BN <= 128 || n0 + row0 + i * RSTEP < n_rows;
     const int x_dst = kt_own * BM * 64, w_dst = KT * BM * 64 + kt_own * BN * 64;
 
     // tap position of this thread's k column (advances by one stage per load)
@@ -126,7 +170,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < WC; ++i)
-            wr[i] = k_ok ? *reinterpret_cast<const uint4*>(w_src + (long long)i * RSTEP * a.K) : make_uint4(0, 0, 0, 0);
+            wr[i] = k_ok && w_ok[i] ? *reinterpret_cast<const uint4*>(w_src + (long long)i * RSTEP * a.K) : make_uint4(0, 0, 0, 0);
         w_src += KT * EPR;
         k_cur += KT * EPR;
         c0 += KT * EPR;
@@ -142,6 +186,75 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         for (int i = 0; i < WC; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_dst + lds_off(row0 + i * RSTEP, q_own)) = wr[i];
     };
 
+    // ---- direct-to-LDS staging state: instruction j of this wave fills unit u = NW*j + wave ----
+    constexpr int NXI = GLDS ? KT * (BM / 16) / NW : 1, NWI = GLDS ? KT * (BN / 16) / NW : 1;
+    static_assert(!GLDS || ((KT * (BM / 16)) % NW == 0 && (KT * (BN / 16)) % NW == 0), "units per wave");
+    long long gx_img[NXI];
+    int gx_h[NXI], gx_w[NXI], gx_k[NXI], gx_c0[NXI], gx_kh[NXI], gx_kw[NXI], gx_lds[NXI];
+    bool gx_ok[NXI];
+    const T* gw_src[NWI];
+    int gw_k[NWI], gw_lds[NWI];
+    bool gw_ok[NWI];
+    if constexpr (GLDS) {
+        const int lrow = lane >> 2, slot = lane & 3;
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            const int u = NW * j + wave, kt = u / (BM / 16), rg = u % (BM / 16), row = rg * 16 + lrow;
+            const int qs = slot ^ (((row >> 3) & 1) << 1);
+            int m = m0 + row;
+            gx_ok[j] = m < a.M;
+            m = gx_ok[j] ? m : a.M - 1;
+            const int b = m / a.OHW, r = m - b * a.OHW, oh = r / a.OW, ow = r - oh * a.OW;
+            gx_img[j] = (long long)b * a.img_stride + qs * VEC;
+            gx_h[j] = oh * a.stride - a.pad_h;
+            gx_w[j] = ow * a.stride - a.pad_w;
+            gx_k[j] = kt * EPR;
+            const int tap = gx_k[j] / a.run;
+            gx_c0[j] = gx_k[j] - tap * a.run;
+            gx_kh[j] = tap / a.kw_taps;
+            gx_kw[j] = tap - gx_kh[j] * a.kw_taps;
+            gx_lds[j] = kt * BM * 64 + rg * 1024;
+        }
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+            const int u = NW * j + wave, kt = u / (BN / 16), rg = u % (BN / 16), row = rg * 16 + lrow;
+            const int qs = slot ^ (((row >> 3) & 1) << 1);
+            gw_k[j] = kt * EPR;
+            gw_ok[j] = BN <= 128 || n0 + row < n_rows;
+            gw_src[j] = w + (long long)(n0 + row) * a.K + kt * EPR + qs * VEC;
+            gw_lds[j] = KT * BM * 64 + kt * BN * 64 + rg * 1024;
+        }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    auto issue_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            const int ih = gx_h[j] + gx_kh[j], iw = gx_w[j] + gx_kw[j];
+            const bool ok = gx_k[j] < a.K && gx_ok[j] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+            const void* p = ok ? (const void*)(in + gx_img[j] + (long long)ih * a.row_stride + (long long)iw * a.pix_stride + gx_c0[j])
+                               : (const void*)g_zero16;
+            glds16(p, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * STAGE + gx_lds[j])));
+            gx_k[j] += KT * EPR;
+            gx_c0[j] += KT * EPR;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {  // run >= one 64-byte sub-tile, so at most KT taps are crossed
+                const bool wrap = gx_c0[j] >= a.run;
+                gx_c0[j] -= wrap ? a.run : 0;
+                gx_kw[j] += wrap ? 1 : 0;
+                const bool roll = gx_kw[j] == a.kw_taps;
+                gx_kw[j] = roll ? 0 : gx_kw[j];
+                gx_kh[j] += roll ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+            const void* p = gw_k[j] < a.K && gw_ok[j] ? (const void*)gw_src[j] : (const void*)g_zero16;
+            glds16(p, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * STAGE + gw_lds[j])));
+            gw_src[j] += KT * EPR;
+            gw_k[j] += KT * EPR;
+        }
+    };
+
     f32x4_t acc[TN][TM];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -150,18 +263,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     int xf_off[TM], wf_off[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) xf_off[i] = lds_off(wm * (BM / 2) + i * 16 + (lane & 15), lane >> 4);
+    for (int i = 0; i < TM; ++i) xf_off[i] = lds_off(wm * RW + i * 16 + (lane & 15), lane >> 4);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) wf_off[j] = KT * BM * 64 + lds_off(wn * (BN / 2) + j * 16 + (lane & 15), lane >> 4);
+    for (int j = 0; j < TN; ++j) wf_off[j] = KT * BM * 64 + lds_off(wn * CW + j * 16 + (lane & 15), lane >> 4);
 
-    load_stage();
-    store_stage(0);
-    __syncthreads();
-    int cur = 0;
-    for (int st = 0; st < a.nk; ++st) {
-        const bool more = st + 1 < a.nk;
-        if (more) load_stage();
-        const unsigned char* base = smem + cur * STAGE;
+    constexpr int PASS_ROWS_ = PASS_ROWS, NPASS_ = BM / PASS_ROWS_, CPR_ = BN / 8, CHUNKS_ = PASS_ROWS_ * CPR_ / NT;
+    uint4 rpre[RES_PRE ? NPASS_ * CHUNKS_ : 1];
+    if constexpr (RES_PRE) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS_; ++pass)
+#pragma unroll
+            for (int i = 0; i < CHUNKS_; ++i) {
+                const int c = tid + i * NT, r = c / CPR_, ch = c - r * CPR_;
+                const int m = m0 + pass * PASS_ROWS_ + r, n = n0 + ch * 8;
+                rpre[pass * CHUNKS_ + i] = (m < a.M && n + 7 < a.N)
+                                               ? *reinterpret_cast<const uint4*>((const bf16_t*)a.res + (long long)m * a.ld_res + n)
+                                               : make_uint4(0, 0, 0, 0);
+            }
+    }
+
+    auto compute_stage = [&](int buf) {
+        const unsigned char* base = smem + buf * STAGE;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             uint4 xf[TM], wf[TN];
@@ -174,9 +296,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
         }
-        if (more) store_stage(cur ^ 1);
+    };
+    if constexpr (GLDS) {
+        constexpr int G = NXI + NWI;  // direct-to-LDS instructions per wave per stage
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) issue_stage(s);
+        int cur = 0, fill = NS - 1;
+        for (int st = 0; st < a.nk; ++st) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * G) : "memory");
+            issue_stage(fill);
+            compute_stage(cur);
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            fill = fill + 1 == NS ? 0 : fill + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        cur ^= 1;
+    } else {
+        load_stage();
+        store_stage(0);
+        __syncthreads();
+        int cur = 0;
+        for (int st = 0; st < a.nk; ++st) {
+            const bool more = st + 1 < a.nk;
+            if (more) load_stage();
+            compute_stage(cur);
+            if (more) store_stage(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // Epilogue through LDS: each lane holds channels n..n+3 of pixel m per 16x16 tile; staging the
@@ -185,23 +332,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     float* sC = reinterpret_cast<float*>(smem);
     constexpr int NPASS = BM / PASS_ROWS;
     constexpr int CPR = BN / 8;                    // 8-channel chunks per row
-    constexpr int CHUNKS = PASS_ROWS * CPR / 256;  // per thread per pass
+    constexpr int CHUNKS = PASS_ROWS * CPR / NT;  // per thread per pass
+    static_assert((PASS_ROWS * CPR) % NT == 0, "epilogue chunks per thread");
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         if (NPASS == 1 || wm == pass) {
-            const int rbase = NPASS == 1 ? wm * (BM / 2) : 0;
+            const int rbase = NPASS == 1 ? wm * RW : 0;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int r = rbase + i * 16 + (lane & 15), cidx = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                    const int r = rbase + i * 16 + (lane & 15), cidx = wn * CW + j * 16 + (lane >> 4) * 4;
                     *reinterpret_cast<f32x4_t*>(sC + r * LDC_S + cidx) = acc[j][i];
                 }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < CHUNKS; ++i) {
-            const int c = tid + i * 256, r = c / CPR, ch = c - r * CPR;
+            const int c = tid + i * NT, r = c / CPR, ch = c - r * CPR;
             const int m = m0 + pass * PASS_ROWS + r, n = n0 + ch * 8;
             if (m >= a.M || n >= a.N) continue;
             float v[8];
@@ -223,7 +371,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                         if (n + e < a.N) v[e] += a.bias[n + e];
                 }
             }
-            if (a.res) {
+            if (RES_PRE && full) {
+                const Vec16<bf16_t> t = __builtin_bit_cast(Vec16<bf16_t>, rpre[pass * CHUNKS + i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)t.v[e];
+            } else if (a.res) {
                 const long long ro = (long long)m * a.ld_res + n;
                 if (a.res_dtype == MIC_F32) {
                     const float* rp = (const float*)a.res + ro;
@@ -296,7 +448,8 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 bool g_prof_on = false;
 
-template <typename T, int BM, int BN, int KT> int launch(IgemmArgs& a, hipStream_t s, double flops) {
+template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2>
+int launch(IgemmArgs& a, hipStream_t s, double flops) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     const int grid = a.tiles_m * a.tiles_n;
@@ -309,12 +462,12 @@ template <typename T, int BM, int BN, int KT> int launch(IgemmArgs& a, hipStream
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof_on && g_prof_used < g_prof.size()) {
             rec = &g_prof[g_prof_used++];
-            rec->slot = (BM == 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0);  // all 128-row tiles share a slot
+            rec->slot = (BM >= 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0);  // tiles of 128 rows and more share a slot
             rec->flops = flops;
         }
     }
     if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e0, s));
-    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT>), dim3(grid), dim3(256), 0, s, a);
+    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT, WM, WN, RES_PRE, GLDS, NS>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e1, s));
     return 0;
 }
@@ -332,12 +485,53 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
         // through occupancy unless K is long; N <= 64 wastes half of a 128-wide tile; problems with
         // few tiles take 64x64 tiles, deeper stages when there are fewer of them than CUs
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-        if (t128 >= 192) {
+        const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        if (t256 >= 192 && a.N % 256 == 0 && a.K >= 1024) {
+            v = 16;  // long K, enough 256x256 tiles for most CUs: half the operand bytes per FLOP
+        } else if (t128 >= 192) {
             if (a.N <= 64) v = 8;
             else v = a.K >= 2048 ? 1 : 0;
         } else {
             const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
             v = t64 > 256 ? 4 : 5;
+        }
+    }
+    static const int res_pre = [] {
+        const char* e = getenv("MIC_IGEMM_RES_PRE");
+        return e ? atoi(e) : 1;
+    }();
+    // residual prefetch variants: bf16 residual with vector-aligned rows, short K (memory-bound layers)
+    if (res_pre && a.res && a.res_dtype == MIC_BF16 && a.vec_ok && a.N % 8 == 0 && a.K <= 64 * res_pre) {
+        if (v == 0) return launch<T, 128, 128, 1, 2, 2, true>(a, s, flops);
+        if (v == 1) return launch<T, 128, 128, 2, 2, 2, true>(a, s, flops);
+    }
+    static const int glds = [] {
+        const char* e = getenv("MIC_IGEMM_GLDS");
+        return e ? atoi(e) : 0;
+    }();
+    if (glds == 1) {
+        switch (v) {
+            case 0: return launch<T, 128, 128, 1, 2, 2, false, true, 4>(a, s, flops);
+            case 1: return launch<T, 128, 128, 2, 2, 2, false, true, 3>(a, s, flops);
+            case 3: return launch<T, 128, 64, 2, 2, 2, false, true, 3>(a, s, flops);
+            case 8: return launch<T, 128, 64, 1, 2, 2, false, true, 4>(a, s, flops);
+            default: break;
+        }
+    } else if (glds == 2) {
+        switch (v) {
+            case 0: return launch<T, 128, 128, 1, 2, 2, false, true, 3>(a, s, flops);
+            case 1: return launch<T, 128, 128, 2, 2, 2, false, true, 2>(a, s, flops);
+            case 3: return launch<T, 128, 64, 2, 2, 2, false, true, 2>(a, s, flops);
+            case 8: return launch<T, 128, 64, 1, 2, 2, false, true, 3>(a, s, flops);
+            default: break;
+        }
+    } else if (glds == 3) {
+        switch (v) {
+            case 0: return launch<T, 128, 128, 1, 2, 2, false, true, 6>(a, s, flops);
+            case 1: return launch<T, 128, 128, 2, 2, 2, false, true, 4>(a, s, flops);
+            case 3: return launch<T, 128, 64, 2, 2, 2, false, true, 4>(a, s, flops);
+            case 8: return launch<T, 128, 64, 1, 2, 2, false, true, 6>(a, s, flops);
+            default: break;
         }
     }
     switch (v) {
@@ -350,6 +544,15 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
         case 6: return launch<T, 64, 64, 8>(a, s, flops);
         case 7: return launch<T, 128, 64, 4>(a, s, flops);
         case 8: return launch<T, 128, 64, 1>(a, s, flops);
+        case 9: return launch<T, 256, 128, 1, 4, 2>(a, s, flops);
+        case 10: return launch<T, 256, 128, 2, 4, 2>(a, s, flops);
+        case 11: return launch<T, 128, 256, 1, 2, 4>(a, s, flops);
+        case 12: return launch<T, 256, 256, 1, 4, 4>(a, s, flops);
+        case 13: return launch<T, 256, 256, 2, 4, 4>(a, s, flops);
+        case 14: return launch<T, 256, 128, 1, 4, 2, false, true, 3>(a, s, flops);
+        case 15: return launch<T, 256, 256, 1, 4, 4, false, true, 3>(a, s, flops);
+        case 16: return launch<T, 256, 256, 2, 4, 4, false, true, 2>(a, s, flops);
+        case 17: return launch<T, 256, 64, 1, 4, 1>(a, s, flops);
         default: mic_set_error("mic_conv2d: unknown tile variant %d", v); return MIC_ERR_ARG;
     }
 }

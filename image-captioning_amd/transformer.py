@@ -22,7 +22,7 @@ from .vocabulary import EOS, PAD, SOS
 
 class ImageCaptioner:
     def __init__(self, vocab, num_heads: int = 2, dtype: torch.dtype = torch.bfloat16, encoder: str = "resnet50",
-                 sync_every: int = 8, use_graph: bool = True):
+                 sync_every: int = 8, use_graph: bool = True, decode_groups: int = 1):
         if encoder not in ("resnet50", "swin", "none"):
             raise ValueError(f"Encoder {encoder} not recognized")
         self.vocab = vocab
@@ -31,6 +31,10 @@ class ImageCaptioner:
         self.encoder_kind = encoder
         self.sync_every = max(1, int(sync_every))
         self.use_graph = bool(use_graph)  # replay each run of decode steps as one HIP graph
+        # beam search over a large batch runs as this many independent sub-batches on their own streams:
+        # the per-step kernels are latency bound, so concurrent sub-batches fill the otherwise idle CUs
+        self.decode_groups = max(1, int(decode_groups))
+        self._side_streams = []
         self._sd = None
         self.device = None
         self.encoder = None
@@ -87,8 +91,8 @@ class ImageCaptioner:
         return self
 
     # ---- workspace ----------------------------------------------------------------------------
-    def _workspace(self, N: int, t_cap: int, S: int, rpi: int, K: int, attn_mode: int):
-        key = (N, t_cap, S, rpi, K, attn_mode)
+    def _workspace(self, N: int, t_cap: int, S: int, rpi: int, K: int, attn_mode: int, slot: int = 0):
+        key = (N, t_cap, S, rpi, K, attn_mode, slot)
         hit = self._ws_cache.get(key)
         if hit is not None:
             return hit
@@ -116,7 +120,7 @@ class ImageCaptioner:
             ws.kcache[l], ws.vcache[l], ws.cross_kv[l] = t["kc"][l].data_ptr(), t["vc"][l].data_ptr(), t["ckv"][l].data_ptr()
         ws.attn = t["attn"].data_ptr() if attn_mode else None
         ws.stats[0], ws.stats[1] = t["stats"][0].data_ptr(), t["stats"][1].data_ptr()
-        if len(self._ws_cache) > 4:
+        if len(self._ws_cache) > 4 * self.decode_groups:
             self._ws_cache.clear()
         self._ws_cache[key] = (ws, t)
         return ws, t
@@ -134,9 +138,37 @@ class ImageCaptioner:
             raise ValueError(f"beam_size must be in [2, {L.MAX_BEAM}], got {beam_size}")
         feats = self._check_feats(feats)
         B, S, _ = feats.shape
+        dev, t_cap = self.device, max_len + 1
+        tokens = torch.empty(B, t_cap, dtype=torch.int32, device=dev)
+        lengths = torch.empty(B, dtype=torch.int32, device=dev)
+        score = torch.empty(B, dtype=torch.float32, device=dev)
+        attn = torch.zeros(B, t_cap, S, dtype=torch.float32, device=dev) if return_attn else None
+        G = min(self.decode_groups, B)
+        if G == 1:
+            self._beam_group(feats, max_len, beam_size, tokens, lengths, score, attn, 0)
+            return tokens, lengths, score, attn
+        while len(self._side_streams) < G:
+            self._side_streams.append(torch.cuda.Stream(device=dev))
+        main = torch.cuda.current_stream(dev)
+        ready = main.record_event()
+        bounds = [(B * g) // G for g in range(G + 1)]
+        for g in range(G):
+            lo, hi = bounds[g], bounds[g + 1]
+            side = self._side_streams[g]
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                self._beam_group(feats[lo:hi], max_len, beam_size, tokens[lo:hi], lengths[lo:hi], score[lo:hi],
+                                 attn[lo:hi] if return_attn else None, g)
+            main.wait_event(side.record_event())
+        return tokens, lengths, score, attn
+
+    def _beam_group(self, feats, max_len, beam_size, tokens, lengths, score, attn, slot):
+        """Beam search of one contiguous sub-batch on the current stream; results go into the given row slices."""
+        return_attn = attn is not None
+        B, S, _ = feats.shape
         K, dev = beam_size, self.device
         N, t_cap = B * K, max_len + 1
-        ws, t = self._workspace(N, t_cap, S, K, K, 1 if return_attn else 0)
+        ws, t = self._workspace(N, t_cap, S, K, K, 1 if return_attn else 0, slot)
         sos = self.vocab.str_to_idx(SOS)
         if "beam" not in t:  # search state lives with the workspace so that repeated calls reuse addresses
             st = (L.BeamState * 2)()
@@ -166,14 +198,9 @@ class ImageCaptioner:
             t0 = t1
             if t0 < max_len and int(live[t0 - 1].item()) == 0:  # every image's beams have ended
                 break
-        tokens = torch.empty(B, t_cap, dtype=torch.int32, device=dev)
-        lengths = torch.empty(B, dtype=torch.int32, device=dev)
-        score = torch.empty(B, dtype=torch.float32, device=dev)
-        attn = torch.zeros(B, t_cap, S, dtype=torch.float32, device=dev) if return_attn else None
         L.check(L.lib.mic_beam_finalize(C.byref(st[t0 & 1]), sqrt_tab.data_ptr(), B, K, t_cap, tokens.data_ptr(), lengths.data_ptr(),
                                         score.data_ptr(), t["attn"].data_ptr() if return_attn else None, S,
                                         L.ptr(attn), stream), "mic_beam_finalize")
-        return tokens, lengths, score, attn
 
     def sample_ids(self, feats: torch.Tensor, max_len: int, temp: Optional[float], return_attn: bool = False,
                    uniforms: Optional[torch.Tensor] = None):

@@ -93,6 +93,24 @@ def test_transformer_golden_without_attn_and_sync_every_step(amd, golden_transfo
     assert len(out) == 2 and out[0] == _rows(g["gen/eos/S49/T30/beam3/tokens"])
 
 
+@pytest.mark.parametrize("groups", [2, 3, 7])
+def test_transformer_beam_in_concurrent_sub_batches(amd, golden_transformer, groups):
+    """Beam search split into sub-batches on side streams returns exactly what one batch returns (golden
+    ids, scores, attention), also when there are more groups than images."""
+    from oracle import captioner_oracle as O
+    g = golden_transformer
+    model = _tr_model(amd, g, "eos_late")
+    model.decode_groups = groups
+    feats = O.tokens_major(torch.from_numpy(g["gen/eos_late/S49/features"]))
+    for K in (3, 5):
+        caps, lp, attn = model.generate_from_features(feats, model.vocab, 30, None, K, True)
+        assert caps == _rows(g[f"gen/eos_late/S49/T30/beam{K}/tokens"])
+        np.testing.assert_allclose(lp.cpu().numpy(), g[f"gen/eos_late/S49/T30/beam{K}/logp"], **F32_TOL)
+        ref = g[f"gen/eos_late/S49/T30/beam{K}/attn"]
+        for i, a in enumerate(attn):
+            np.testing.assert_allclose(np.array(a, dtype=np.float32), ref[i, : len(a)], **F32_TOL)
+
+
 @pytest.mark.parametrize("S", [49, 64])
 def test_transformer_teacher_forced_logits_fp32(amd, golden_transformer, S):
     """Stepping the cached decoder over a fixed caption reproduces the reference's full-prefix logits."""

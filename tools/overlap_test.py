@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Development aid: does the encoder of batch i+1 overlap with the beam search of batch i when they
+run on two streams?  Prints ms per batch for the sequential and the two-stream schedule."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import image_captioning_amd as amd  # noqa: E402
+
+dev = torch.device("cuda:0")
+sd = bench.build_state()
+vocab = amd.Vocabulary.synthetic(bench.V)
+model = amd.transformer.ImageCaptioner(vocab, bench.HEADS, torch.bfloat16, sync_every=bench.MAX_LEN).load_state_dict(sd).to(dev)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+images = torch.randn(B, 3, 224, 224, device=dev)
+K = 8
+
+
+def sequential():
+    for _ in range(K):
+        feats = model.encode(images)
+        model.beam_search_ids(feats, bench.MAX_LEN, bench.BEAM)
+
+
+side = torch.cuda.Stream()
+
+
+def pipelined():
+    main = torch.cuda.current_stream()
+    feats = model.encode(images)
+    for i in range(K):
+        nxt = None
+        if i + 1 < K:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                nxt = model.encode(images)
+        model.beam_search_ids(feats, bench.MAX_LEN, bench.BEAM)
+        main.wait_stream(side)
+        feats = nxt
+
+
+for name, fn in (("sequential", sequential), ("pipelined", pipelined), ("sequential", sequential), ("pipelined", pipelined)):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    print(f"{name:11s} {(time.perf_counter() - t0) / K * 1e3:7.3f} ms per batch of {B}", flush=True)
