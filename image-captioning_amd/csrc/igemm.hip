@@ -91,7 +91,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
 // FLOP fall as (BM + BN) / (BM * BN): the kernel is bound by the per-CU fill rate (L2 -> LDS) well
 // before the MFMA rate, so the large-M layers take 256-row tiles with 8 waves.
 template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, NT = 64 * NW;  // waves, threads
     constexpr int RW = BM / WM, CW = BN / WN;  // rows / columns per wave
     constexpr int VEC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
@@ -501,7 +501,7 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
         return e ? atoi(e) : 1;
     }();
     // residual prefetch variants: bf16 residual with vector-aligned rows, short K (memory-bound layers)
-    if (res_pre && a.res && a.res_dtype == MIC_BF16 && a.vec_ok && a.N % 8 == 0 && a.K <= 64 * res_pre) {
+    if (res_pre && a.res && a.res_dtype == MIC_BF16 && a.vec_ok && a.N % 8 == 0 && a.K <= 128 * res_pre) {
         if (v == 0) return launch<T, 128, 128, 1, 2, 2, true>(a, s, flops);
         if (v == 1) return launch<T, 128, 128, 2, 2, 2, true>(a, s, flops);
     }

@@ -108,6 +108,80 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
     (void)winner;
 }
 
+// Same result for rows of at most 256 * R entries, read from memory ONCE: every load of the row is issued
+// up front (one memory round trip instead of three passes of dependent ones) and the maximum, the sum
+// and the selection all work on registers.
+template <int K, int R>
+__global__ __launch_bounds__(256) void logsoftmax_topk_reg_kernel(const float* __restrict__ logits, int ld, int V, float inv_temp,
+                                                                  int rank_raw, float* __restrict__ out_val,
+                                                                  int32_t* __restrict__ out_idx, float* __restrict__ lse) {
+    __shared__ float red[4];
+    __shared__ KV wbest[4];
+    const int tid = threadIdx.x;
+    const float* x = logits + (long long)blockIdx.x * ld;
+    float raw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + 256 * r;
+        raw[r] = i < V ? x[i] : -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m = fmaxf(m, raw[r] * inv_temp);
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (tid + 256 * r < V) s += expf(raw[r] * inv_temp - m);
+    s = block_sum(s, red);
+    const float logs = logf(s);
+    if (lse && tid == 0) lse[blockIdx.x] = m + logs;
+
+    KV loc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) loc[k] = KV{-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + 256 * r;
+        if (i < V) {
+            KV c{rank_raw ? raw[r] : (raw[r] * inv_temp - m) - logs, i};
+            if (before(c, loc[K - 1])) {
+                loc[K - 1] = c;
+#pragma unroll
+                for (int k = K - 1; k > 0; --k) {
+                    if (before(loc[k], loc[k - 1])) {
+                        const KV t = loc[k - 1];
+                        loc[k - 1] = loc[k];
+                        loc[k] = t;
+                    }
+                }
+            }
+        }
+    }
+    for (int r = 0; r < K; ++r) {
+        const KV b = wave_best(loc[0]);
+        if ((tid & 63) == 0) wbest[tid >> 6] = b;
+        __syncthreads();
+        KV best = wbest[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (before(wbest[w], best)) best = wbest[w];
+        if (loc[0].idx == best.idx && best.idx != 0x7fffffff) {
+            // this thread owned the winner: emit (always as a log-probability) and pop
+            const float xs = x[best.idx] * inv_temp;
+            out_val[(long long)blockIdx.x * K + r] = (xs - m) - logs;
+            out_idx[(long long)blockIdx.x * K + r] = best.idx;
+#pragma unroll
+            for (int k = 0; k < K - 1; ++k) loc[k] = loc[k + 1];
+            loc[K - 1] = KV{-INFINITY, 0x7fffffff};
+        } else if (best.idx == 0x7fffffff && tid == 0) {
+            out_val[(long long)blockIdx.x * K + r] = -INFINITY;  // fewer than K entries in the row
+            out_idx[(long long)blockIdx.x * K + r] = 0;
+        }
+        __syncthreads();
+    }
+}
+
 // one 256-thread workgroup per row; thread i owns the contiguous slice [i*chunk, (i+1)*chunk)
 __global__ __launch_bounds__(256) void sample_multinomial_kernel(const float* __restrict__ logits, int ld, int V, float inv_temp,
                                                                  const float* __restrict__ u, float* __restrict__ out_val,
@@ -312,8 +386,12 @@ extern "C" int mic_logsoftmax_topk(const float* logits, int ld, int N, int V, in
     hipStream_t s = (hipStream_t)stream;
 #define MIC_TOPK_CASE(KK)                                                                                                  \
     case KK:                                                                                                               \
-        MIC_LAUNCH(logsoftmax_topk_kernel<KK>, dim3(N), dim3(256), 0, s, logits, ld, V, inv_temp, rank_raw, out_val, \
-                           out_idx, lse);                                                                                  \
+        if (V <= 256 * 16)                                                                                                 \
+            MIC_LAUNCH((logsoftmax_topk_reg_kernel<KK, 16>), dim3(N), dim3(256), 0, s, logits, ld, V, inv_temp, rank_raw,  \
+                       out_val, out_idx, lse);                                                                             \
+        else                                                                                                               \
+            MIC_LAUNCH(logsoftmax_topk_kernel<KK>, dim3(N), dim3(256), 0, s, logits, ld, V, inv_temp, rank_raw, out_val,   \
+                       out_idx, lse);                                                                                      \
         break;
     switch (K) {
         MIC_TOPK_CASE(1) MIC_TOPK_CASE(2) MIC_TOPK_CASE(3) MIC_TOPK_CASE(4)

@@ -43,35 +43,35 @@ def gather_captions(tokens: torch.Tensor, lengths: torch.Tensor, scores: torch.T
     """Final exchange: every rank contributes its shard's int32 token matrix (n_local, T), lengths and
     fp32 scores; returns the concatenation over ranks in rank order, trimmed to n_total rows
     (on every rank, or only on `dst` when given; other ranks get None).  Shards are padded to the
-    per-rank maximum so one fixed-size collective per tensor suffices."""
+    per-rank maximum and packed so that one fixed-size collective carries everything."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return tokens[:n_total], lengths[:n_total], scores[:n_total]
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n_total + world - 1) // world
     T = tokens.shape[1]
-
-    def pad(t, fill):
-        if t.shape[0] == per:
-            return t.contiguous()
-        out = torch.full((per,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)
-        out[: t.shape[0]] = t
-        return out
-
-    outs = []
-    for t, fill in ((tokens, -1), (lengths, 0), (scores, 0.0)):
-        p = pad(t, fill)
-        if dst is None:
-            buf = torch.empty((world * per,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
-            if dist.get_backend() == "nccl":
-                dist.all_gather_into_tensor(buf, p)
-            else:
-                parts = [torch.empty_like(p) for _ in range(world)]
-                dist.all_gather(parts, p)
-                buf = torch.cat(parts, dim=0)
-            outs.append(buf[:n_total])
+    # one message per rank: [per][T + 2] int32 = token ids | length | score bits, so the whole exchange
+    # is a single collective (its latency, not its 4*(T+2) bytes per image, is what a step pays)
+    pack = torch.empty(per, T + 2, dtype=torch.int32, device=tokens.device)
+    n = tokens.shape[0]
+    pack[:n, :T] = tokens
+    pack[:n, T] = lengths
+    pack[:n, T + 1] = scores.to(torch.float32).contiguous().view(torch.int32)
+    if n < per:
+        pack[n:, :T] = -1
+        pack[n:, T:] = 0
+    if dst is None:
+        buf = torch.empty(world * per, T + 2, dtype=torch.int32, device=pack.device)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(buf, pack)
         else:
-            parts = [torch.empty_like(p) for _ in range(world)] if rank == dst else None
-            dist.gather(p, parts, dst=dst)
-            outs.append(torch.cat(parts, dim=0)[:n_total] if rank == dst else None)
-    assert T == tokens.shape[1]
-    return tuple(outs)
+            parts = [torch.empty_like(pack) for _ in range(world)]
+            dist.all_gather(parts, pack)
+            buf = torch.cat(parts, dim=0)
+    else:
+        parts = [torch.empty_like(pack) for _ in range(world)] if rank == dst else None
+        dist.gather(pack, parts, dst=dst)
+        if rank != dst:
+            return None, None, None
+        buf = torch.cat(parts, dim=0)
+    buf = buf[:n_total]
+    return buf[:, :T].contiguous(), buf[:, T].contiguous(), buf[:, T + 1].contiguous().view(torch.float32)

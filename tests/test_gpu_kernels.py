@@ -245,7 +245,7 @@ def test_attention_steps(L, dtype, H, heads):
     np.testing.assert_allclose(attn.cpu().numpy(), 0.25 + 0.5 * wref.numpy(), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("V", [200, 3500, 6501])
+@pytest.mark.parametrize("V", [200, 3500, 4096, 4097, 6501])
 @pytest.mark.parametrize("K", [1, 3, 5, 8])
 def test_logsoftmax_topk(L, V, K):
     g = torch.Generator().manual_seed(V + K)
