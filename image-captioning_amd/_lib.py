@@ -25,7 +25,9 @@ class ConvDesc(C.Structure):
                 ("in_img_stride", i64), ("in_row_stride", i64),
                 ("in_pix_stride", i32), ("kw_taps", i32), ("run", i32),
                 ("stride", i32), ("pad_h", i32), ("pad_w", i32),
-                ("ldc", i32), ("ld_res", i32), ("relu", i32), ("k_valid", i32)]
+                ("ldc", i32), ("ld_res", i32), ("relu", i32), ("k_valid", i32),
+                ("in2", vp), ("in2_img_stride", i64), ("in2_row_stride", i64),
+                ("in2_pix_stride", i32), ("stride2", i32), ("K2", i32)]
 
 
 class LnRef(C.Structure):
@@ -47,8 +49,13 @@ class ConvLayer(C.Structure):
                 ("stride", i32), ("pad", i32), ("relu", i32)]
 
 
+class FusedTail(C.Structure):
+    _fields_ = [("w", vp), ("bias", vp), ("cin_main", i32), ("cin_skip", i32), ("cout", i32), ("skip_stride", i32)]
+
+
 class Resnet50(C.Structure):
-    _fields_ = [("dtype", i32), ("stem", ConvLayer), ("blocks_per_stage", i32 * 4), ("conv", (ConvLayer * 4) * 16)]
+    _fields_ = [("dtype", i32), ("stem", ConvLayer), ("blocks_per_stage", i32 * 4), ("conv", (ConvLayer * 4) * 16),
+                ("tail", FusedTail * 4)]
 
 
 SWIN_MAX_BLOCKS = 32

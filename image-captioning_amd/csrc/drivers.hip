@@ -171,12 +171,31 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
             MIC_TRY(conv_layer(dt, L[0], X[cur], B, h, w, nullptr, T1, &h1, &w1, s));
             MIC_TRY(conv_layer(dt, L[1], T1, B, h1, w1, nullptr, T2, &h2, &w2, s));
             const void* idt = X[cur];
+            void* dst = (bi == nblocks - 1) ? out : X[cur ^ 1];
+            const mic_fused_tail& F = net->tail[st];
+            if (k == 0 && L[3].cout > 0 && F.w) {
+                // conv3 + shortcut convolution + ReLU as one GEMM over [T2 | strided X]
+                MIC_ARG_CHECK(F.cin_main == L[2].cin && F.cin_skip == L[3].cin && F.cout == L[2].cout && F.skip_stride == L[3].stride,
+                              "mic_resnet50_forward: fused tail of stage %d does not match its conv3 / downsample", st);
+                mic_conv_desc d{};
+                d.in = T2; d.w = F.w; d.bias = F.bias; d.out = dst;
+                d.dtype = d.out_dtype = d.res_dtype = dt;
+                d.M = B * h2 * w2; d.N = F.cout; d.K = F.cin_main;
+                d.OH = h2; d.OW = w2; d.IH = h2; d.IW = w2;
+                d.in_img_stride = (int64_t)h2 * w2 * F.cin_main; d.in_row_stride = (int64_t)w2 * F.cin_main; d.in_pix_stride = F.cin_main;
+                d.kw_taps = 1; d.run = F.cin_main; d.stride = 1;
+                d.ldc = F.cout; d.relu = 1;
+                d.in2 = X[cur]; d.K2 = F.cin_skip; d.stride2 = F.skip_stride;
+                d.in2_img_stride = (int64_t)h * w * F.cin_skip; d.in2_row_stride = (int64_t)w * F.cin_skip; d.in2_pix_stride = F.cin_skip;
+                MIC_TRY(mic_conv2d(&d, s));
+                cur ^= 1; h = h2; w = w2;
+                continue;
+            }
             if (L[3].cout > 0) {
                 int hd, wd;
                 MIC_TRY(conv_layer(dt, L[3], X[cur], B, h, w, nullptr, DS, &hd, &wd, s));
                 idt = DS;
             }
-            void* dst = (bi == nblocks - 1) ? out : X[cur ^ 1];
             MIC_TRY(conv_layer(dt, L[2], T2, B, h2, w2, idt, dst, &h3, &w3, s));
             cur ^= 1; h = h3; w = w3;
         }

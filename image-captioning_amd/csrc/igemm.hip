@@ -32,6 +32,11 @@ struct IgemmArgs {
     int pix_stride, kw_taps, run, stride, pad_h, pad_w;
     int ldc, ld_res, relu, out_dtype, res_dtype;
     int tiles_m, tiles_n, nk, vec_ok;
+    // optional second K segment: k in [K, Kt) reads channel k-K of in2 at pixel (oh*stride2, ow*stride2)
+    const void* in2;
+    int K2, Kt;
+    long long img_stride2, row_stride2;
+    int pix_stride2, stride2;
 };
 
 // LDS tile image: rows of 64 bytes (4 chunks of 16 B).  Chunk q of row r is stored at chunk
@@ -90,7 +95,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
 // A workgroup is WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile.  Operand bytes fetched per
 // FLOP fall as (BM + BN) / (BM * BN): the kernel is bound by the per-CU fill rate (L2 -> LDS) well
 // before the MFMA rate, so the large-M layers take 256-row tiles with 8 waves.
-template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2>
+// SEG2: the K range continues into a second input tensor (see IgemmArgs::in2); compiled in only for
+// the variants the fused bottleneck tails use, because its extra row pointers cost the plain kernels
+// a step of occupancy.
+template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false>
 __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, NT = 64 * NW;  // waves, threads
     constexpr int RW = BM / WM, CW = BN / WN;  // rows / columns per wave
@@ -132,6 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
     long long x_img[XC];
     int x_h[XC], x_w[XC];
     bool x_ok[XC];
+    const T* x2_p[SEG2 ? XC : 1];
 #pragma unroll
     for (int i = 0; i < XC; ++i) {
         int m = m0 + row0 + i * RSTEP;
@@ -141,8 +150,11 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
         x_img[i] = (long long)b * a.img_stride + q_own * VEC;
         x_h[i] = oh * a.stride - a.pad_h;
         x_w[i] = ow * a.stride - a.pad_w;
+        if constexpr (SEG2)
+            x2_p[i] = (const T*)a.in2 + (long long)b * a.img_stride2 + (long long)(oh * a.stride2) * a.row_stride2 +
+                      (long long)(ow * a.stride2) * a.pix_stride2 + q_own * VEC;
     }
-    const T* w_src = w + (long long)(n0 + row0) * a.K + kt_own * EPR + q_own * VEC;
+    const T* w_src = w + (long long)(n0 + row0) * a.Kt + kt_own * EPR + q_own * VEC;
     // weight matrices are padded to a multiple of 128 rows: tiles wider than that must not read past it
     const int n_rows = (a.N + 127) & ~127;
     bool w_ok[WC];
@@ -160,17 +172,23 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
     }
     uint4 xr[XC], wr[WC];
     auto load_stage = [&]() {
-        const bool k_ok = k_cur < a.K;
+        const bool k_ok = k_cur < a.Kt;
+        if (!SEG2 || k_cur < a.K) {
 #pragma unroll
-        for (int i = 0; i < XC; ++i) {
-            const int ih = x_h[i] + kh, iw = x_w[i] + kw;
-            const bool ok = k_ok && x_ok[i] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
-            const T* p = in + x_img[i] + (long long)ih * a.row_stride + (long long)iw * a.pix_stride + c0;
-            xr[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < XC; ++i) {
+                const int ih = x_h[i] + kh, iw = x_w[i] + kw;
+                const bool ok = k_ok && x_ok[i] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+                const T* p = in + x_img[i] + (long long)ih * a.row_stride + (long long)iw * a.pix_stride + c0;
+                xr[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+            }
+        } else if constexpr (SEG2) {  // second segment (or past the end: zeros)
+#pragma unroll
+            for (int i = 0; i < XC; ++i)
+                xr[i] = k_ok && x_ok[i] ? *reinterpret_cast<const uint4*>(x2_p[i] + (k_cur - a.K)) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WC; ++i)
-            wr[i] = k_ok && w_ok[i] ? *reinterpret_cast<const uint4*>(w_src + (long long)i * RSTEP * a.K) : make_uint4(0, 0, 0, 0);
+            wr[i] = k_ok && w_ok[i] ? *reinterpret_cast<const uint4*>(w_src + (long long)i * RSTEP * a.Kt) : make_uint4(0, 0, 0, 0);
         w_src += KT * EPR;
         k_cur += KT * EPR;
         c0 += KT * EPR;
@@ -192,6 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
     long long gx_img[NXI];
     int gx_h[NXI], gx_w[NXI], gx_k[NXI], gx_c0[NXI], gx_kh[NXI], gx_kw[NXI], gx_lds[NXI];
     bool gx_ok[NXI];
+    const T* gx2_p[SEG2 ? NXI : 1];
     const T* gw_src[NWI];
     int gw_k[NWI], gw_lds[NWI];
     bool gw_ok[NWI];
@@ -214,6 +233,9 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
             gx_kh[j] = tap / a.kw_taps;
             gx_kw[j] = tap - gx_kh[j] * a.kw_taps;
             gx_lds[j] = kt * BM * 64 + rg * 1024;
+            if constexpr (SEG2)
+                gx2_p[j] = (const T*)a.in2 + (long long)b * a.img_stride2 + (long long)(oh * a.stride2) * a.row_stride2 +
+                           (long long)(ow * a.stride2) * a.pix_stride2 + qs * VEC;
         }
 #pragma unroll
         for (int j = 0; j < NWI; ++j) {
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
             const int qs = slot ^ (((row >> 3) & 1) << 1);
             gw_k[j] = kt * EPR;
             gw_ok[j] = BN <= 128 || n0 + row < n_rows;
-            gw_src[j] = w + (long long)(n0 + row) * a.K + kt * EPR + qs * VEC;
+            gw_src[j] = w + (long long)(n0 + row) * a.Kt + kt * EPR + qs * VEC;
             gw_lds[j] = KT * BM * 64 + kt * BN * 64 + rg * 1024;
         }
     }
@@ -230,9 +252,11 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
 #pragma unroll
         for (int j = 0; j < NXI; ++j) {
             const int ih = gx_h[j] + gx_kh[j], iw = gx_w[j] + gx_kw[j];
-            const bool ok = gx_k[j] < a.K && gx_ok[j] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
-            const void* p = ok ? (const void*)(in + gx_img[j] + (long long)ih * a.row_stride + (long long)iw * a.pix_stride + gx_c0[j])
-                               : (const void*)g_zero16;
+            const bool seg1 = gx_k[j] < a.K;
+            const bool ok = gx_ok[j] && (seg1 ? (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW : SEG2 && gx_k[j] < a.Kt);
+            const void* p = !ok    ? (const void*)g_zero16
+                            : seg1 ? (const void*)(in + gx_img[j] + (long long)ih * a.row_stride + (long long)iw * a.pix_stride + gx_c0[j])
+                                   : (const void*)(gx2_p[SEG2 ? j : 0] + (gx_k[j] - a.K));
             glds16(p, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * STAGE + gx_lds[j])));
             gx_k[j] += KT * EPR;
             gx_c0[j] += KT * EPR;
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
         }
 #pragma unroll
         for (int j = 0; j < NWI; ++j) {
-            const void* p = gw_k[j] < a.K && gw_ok[j] ? (const void*)gw_src[j] : (const void*)g_zero16;
+            const void* p = gw_k[j] < a.Kt && gw_ok[j] ? (const void*)gw_src[j] : (const void*)g_zero16;
             glds16(p, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * STAGE + gw_lds[j])));
             gw_src[j] += KT * EPR;
             gw_k[j] += KT * EPR;
@@ -448,13 +472,13 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 bool g_prof_on = false;
 
-template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2>
+template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false>
 int launch(IgemmArgs& a, hipStream_t s, double flops) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     const int grid = a.tiles_m * a.tiles_n;
     constexpr int kstage = KT * 64 / (int)sizeof(T);
-    a.nk = (a.K + kstage - 1) / kstage;
+    a.nk = (a.Kt + kstage - 1) / kstage;
     ProfRec* rec = nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (g_prof_on) (void)hipStreamIsCapturing(s, &cap);
@@ -467,7 +491,7 @@ int launch(IgemmArgs& a, hipStream_t s, double flops) {
         }
     }
     if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e0, s));
-    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT, WM, WN, RES_PRE, GLDS, NS>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
+    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT, WM, WN, RES_PRE, GLDS, NS, SEG2>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e1, s));
     return 0;
 }
@@ -486,14 +510,24 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
         // few tiles take 64x64 tiles, deeper stages when there are fewer of them than CUs
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-        if (t256 >= 192 && a.N % 256 == 0 && a.K >= 1024) {
+        if (t256 >= 192 && a.N % 256 == 0 && a.Kt >= 1024) {
             v = 16;  // long K, enough 256x256 tiles for most CUs: half the operand bytes per FLOP
         } else if (t128 >= 192) {
             if (a.N <= 64) v = 8;
-            else v = a.K >= 2048 ? 1 : 0;
+            else v = a.Kt >= 2048 ? 1 : 0;
         } else {
             const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
             v = t64 > 256 ? 4 : 5;
+        }
+    }
+    if (a.in2) {
+        // two-segment K (fused bottleneck tails): measured on the four ResNet-50 shapes at batch 256
+        const int epr = 64 / (int)sizeof(T);
+        if (forced < 0) v = a.N % 256 != 0 ? 0 : (a.Kt < 256 || a.K % (2 * epr) != 0) ? 11 : 16;
+        switch (v) {
+            case 11: return launch<T, 128, 256, 1, 2, 4, false, false, 2, true>(a, s, flops);
+            case 16: return launch<T, 256, 256, 2, 4, 4, false, true, 2, true>(a, s, flops);
+            default: return launch<T, 128, 128, 1, 2, 2, false, false, 2, true>(a, s, flops);
         }
     }
     static const int res_pre = [] {
@@ -503,7 +537,6 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
     // residual prefetch variants: bf16 residual with vector-aligned rows, short K (memory-bound layers)
     if (res_pre && a.res && a.res_dtype == MIC_BF16 && a.vec_ok && a.N % 8 == 0 && a.K <= 128 * res_pre) {
         if (v == 0) return launch<T, 128, 128, 1, 2, 2, true>(a, s, flops);
-        if (v == 1) return launch<T, 128, 128, 2, 2, 2, true>(a, s, flops);
     }
     static const int glds = [] {
         const char* e = getenv("MIC_IGEMM_GLDS");
@@ -578,9 +611,17 @@ extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
                   "mic_conv2d: input strides / pointers must keep 16-byte alignment");
     // pixel stride may be smaller than a chunk only when chunks still start 16-byte aligned
     MIC_ARG_CHECK((d->in_pix_stride * (int)mic_dtype_size(d->dtype)) % 8 == 0, "mic_conv2d: pixel stride alignment");
+    if (d->in2) {
+        MIC_ARG_CHECK(d->K2 > 0 && d->K2 % epr == 0 && d->K % epr == 0, "mic_conv2d: second segment K2=%d (K=%d) must be multiples of %d", d->K2, d->K, epr);
+        MIC_ARG_CHECK(d->stride2 > 0 && d->in2_pix_stride % vec == 0 && d->in2_row_stride % vec == 0 && d->in2_img_stride % vec == 0 &&
+                          ((uintptr_t)d->in2 & 15) == 0,
+                      "mic_conv2d: second input strides / pointer must keep 16-byte alignment");
+    }
     IgemmArgs a;
     a.in = d->in; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
     a.M = d->M; a.N = d->N; a.K = d->K;
+    a.in2 = d->in2; a.K2 = d->in2 ? d->K2 : 0; a.Kt = a.K + a.K2;
+    a.img_stride2 = d->in2_img_stride; a.row_stride2 = d->in2_row_stride; a.pix_stride2 = d->in2_pix_stride; a.stride2 = d->stride2;
     a.OHW = d->OH * d->OW; a.OW = d->OW; a.IH = d->IH; a.IW = d->IW;
     a.img_stride = d->in_img_stride; a.row_stride = d->in_row_stride;
     a.pix_stride = d->in_pix_stride; a.kw_taps = d->kw_taps; a.run = d->run;
@@ -591,7 +632,7 @@ extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
     a.vec_ok = (d->ldc % 8 == 0) && (((uintptr_t)d->out) % 16 == 0) && (!d->bias || ((uintptr_t)d->bias) % 16 == 0) &&
                (!d->res || (d->ld_res % 8 == 0 && ((uintptr_t)d->res) % 16 == 0));
     hipStream_t s = (hipStream_t)stream;
-    const double flops = 2.0 * d->M * d->N * (d->k_valid > 0 ? d->k_valid : d->K);
+    const double flops = 2.0 * d->M * d->N * ((d->k_valid > 0 ? d->k_valid : d->K) + a.K2);
     return d->dtype == MIC_BF16 ? dispatch<bf16_t>(a, s, flops) : dispatch<float>(a, s, flops);
 }
 

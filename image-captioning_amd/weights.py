@@ -99,7 +99,7 @@ def _conv_layer(keep: Keep, w, bias, dtype, device, stride, pad, relu, stem=Fals
     return L.ConvLayer(keep(wm), keep(vector(bias, device)), ci, co, kh, kw, stride, pad, int(relu))
 
 
-def build_resnet50(sd: SD, prefix: str, dtype: torch.dtype, device) -> tuple:
+def build_resnet50(sd: SD, prefix: str, dtype: torch.dtype, device, fuse_tails: bool = True) -> tuple:
     """torchvision resnet50 children 0..7 under ``prefix`` ('encoder.resnet.') -> mic_resnet50."""
     keep = Keep()
     net = L.Resnet50()
@@ -123,8 +123,16 @@ def build_resnet50(sd: SD, prefix: str, dtype: torch.dtype, device) -> tuple:
             w, b = cb(p + "conv3", p + "bn3")
             net.conv[bi][2] = _conv_layer(keep, w, b, dtype, device, 1, 0, True)  # ReLU after the residual add
             if (p + "downsample.0.weight") in sd:
+                w3, b3 = w, b
                 w, b = cb(p + "downsample.0", p + "downsample.1")
                 net.conv[bi][3] = _conv_layer(keep, w, b, dtype, device, s, 0, False)
+                km = k_multiple(dtype)
+                if fuse_tails and k == 0 and w3.shape[1] % km == 0 and w.shape[1] % km == 0:
+                    # conv3 and the shortcut convolution share one accumulator: [W3 | Wds] over K = width + cin
+                    cat = torch.cat([w3.reshape(w3.shape[0], -1), w.reshape(w.shape[0], -1)], dim=1)
+                    T_ = net.tail[si]
+                    T_.w, T_.bias = keep(matrix(cat, dtype, device)), keep(vector(b3 + b, device))
+                    T_.cin_main, T_.cin_skip, T_.cout, T_.skip_stride = w3.shape[1], w.shape[1], w3.shape[0], s
             bi += 1
     return net, keep
 

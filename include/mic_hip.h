@@ -74,6 +74,14 @@ typedef struct mic_conv_desc {
     int32_t ldc, ld_res;
     int32_t relu;         /* MIC_ACT_* */
     int32_t k_valid;      /* k entries that are not structural zero padding (0 = K); only used for FLOP accounting */
+    /* Optional second K segment (NULL = none): the sum continues over k in [K, K+K2) with
+     * A[m, k] = in2[b, oh*stride2, ow*stride2, k-K] (a 1x1 read, no padding) and W has K+K2 columns.
+     * Fuses the stride-s 1x1 shortcut convolution of a bottleneck's first block into its last
+     * convolution (torchvision Bottleneck.forward: out = conv3(...) + downsample(x)), so the shortcut
+     * never round-trips through memory.  K and K2 must be multiples of 64/sizeof(T). */
+    const void* in2;
+    int64_t in2_img_stride, in2_row_stride;
+    int32_t in2_pix_stride, stride2, K2;
 } mic_conv_desc;
 int mic_conv2d(const mic_conv_desc* d, void* stream);
 
@@ -290,11 +298,20 @@ typedef struct mic_conv_layer {
     int32_t cin, cout, kh, kw, stride, pad, relu;
 } mic_conv_layer;
 
+/* conv3 and the shortcut convolution of a stage's first bottleneck as ONE GEMM over K = cin_main +
+ * cin_skip: w = [conv3 | downsample] column-concatenated (BN folded), bias = their sum. */
+typedef struct mic_fused_tail {
+    const void* w;        /* NULL: run downsample and conv3 separately */
+    const float* bias;
+    int32_t cin_main, cin_skip, cout, skip_stride;
+} mic_fused_tail;
+
 typedef struct mic_resnet50 {
     int32_t dtype;
     mic_conv_layer stem;            /* 7x7/2 as 7 row-taps of 32 over the packed image */
     int32_t blocks_per_stage[4];
     mic_conv_layer conv[16][4];     /* per bottleneck: conv1, conv2, conv3, downsample (cout==0: none) */
+    mic_fused_tail tail[4];         /* optional, per stage */
 } mic_resnet50;
 
 /* Bytes of workspace mic_resnet50_forward needs for a batch. */

@@ -90,6 +90,48 @@ def test_conv2d(L, W, dtype, case):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), **_tol(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [
+    # B, main channels, shortcut channels, H (shortcut input), stride, Co
+    (2, 64, 64, 14, 1, 256),     # short K, N a multiple of 256
+    (3, 128, 256, 15, 2, 512),   # stride-2 shortcut over an odd map, K = 384
+    (2, 64, 32, 9, 2, 96),       # N not a multiple of 256 (128x128 tiles), partial tiles
+    (5, 256, 512, 14, 2, 1024),  # K = 768
+])
+def test_conv2d_second_k_segment(L, W, dtype, case):
+    """out = relu(conv1x1(y) + conv1x1_stride_s(x) + bias): the fused tail of a bottleneck's first block."""
+    B, C1, C2, H, st, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    OH = (H - 1) // st + 1
+    y = torch.randn(B, C1, OH, OH, generator=g)
+    x = torch.randn(B, C2, H, H, generator=g)
+    w1 = torch.randn(Co, C1, 1, 1, generator=g) / math.sqrt(C1)
+    w2 = torch.randn(Co, C2, 1, 1, generator=g) / math.sqrt(C2)
+    b = torch.randn(Co, generator=g)
+    if dtype == torch.bfloat16:
+        y, x, w1, w2 = (t.bfloat16().float() for t in (y, x, w1, w2))
+    ref = F.relu(F.conv2d(y, w1, b) + F.conv2d(x, w2, None, st))
+    yd = y.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wm = W.matrix(torch.cat([w1.reshape(Co, C1), w2.reshape(Co, C2)], dim=1), dtype, DEV)
+    bd = b.to(DEV)
+    out = torch.empty(B, OH, OH, Co, dtype=dtype, device=DEV)
+    d = L.ConvDesc()
+    d.in_, d.w, d.bias, d.out = yd.data_ptr(), wm.data_ptr(), bd.data_ptr(), out.data_ptr()
+    d.dtype = d.out_dtype = d.res_dtype = L.dtype_code(dtype)
+    d.M, d.N, d.K = B * OH * OH, Co, C1
+    d.OH, d.OW, d.IH, d.IW = OH, OH, OH, OH
+    d.in_img_stride, d.in_row_stride, d.in_pix_stride = OH * OH * C1, OH * C1, C1
+    d.kw_taps, d.run, d.stride = 1, C1, 1
+    d.ldc, d.relu = Co, 1
+    d.in2, d.K2, d.stride2 = xd.data_ptr(), C2, st
+    d.in2_img_stride, d.in2_row_stride, d.in2_pix_stride = H * H * C2, H * C2, C2
+    L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()), "mic_conv2d")
+    np.testing.assert_allclose(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), **_tol(dtype))
+    d.K2 = 24  # not a multiple of the k-tile
+    assert L.lib.mic_conv2d(C.byref(d), L.stream_ptr()) == -1
+
+
 def test_conv2d_rejects_bad_arguments(L):
     d = L.ConvDesc()
     assert L.lib.mic_conv2d(C.byref(d), None) == -1

@@ -95,7 +95,7 @@ def main():
         print(f"{nm:12s} M={M:8d} N={N:5d} K={K:5d} {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("ln", "skinny")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("ln", "skinny", "tail")):
     main()
 
 
@@ -156,3 +156,36 @@ def skinny():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "skinny":
     skinny()
+
+
+def tails():
+    """conv3 + shortcut convolution of each stage's first bottleneck as one two-segment GEMM."""
+    dt, B = torch.bfloat16, 256
+    cin, h = 64, 56
+    for si, (wd, st) in enumerate([(64, 1), (128, 2), (256, 2), (512, 2)]):
+        oh = h // st
+        M, N, K1, K2 = B * oh * oh, 4 * wd, wd, cin
+        y2 = torch.randn(M, K1, device=DEV).to(dt)
+        x = torch.randn(B * h * h, K2, device=DEV).to(dt)
+        w = (torch.randn((N + 127) // 128 * 128, K1 + K2, device=DEV) * 0.05).to(dt)
+        bias = torch.randn(N, device=DEV)
+        out = torch.empty(M, N, device=DEV, dtype=dt)
+        d = L.ConvDesc()
+        d.in_, d.w, d.bias, d.out = y2.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr()
+        d.dtype = d.out_dtype = d.res_dtype = L.BF16
+        d.M, d.N, d.K, d.OH, d.OW, d.IH, d.IW = M, N, K1, oh, oh, oh, oh
+        d.in_img_stride, d.in_row_stride, d.in_pix_stride = oh * oh * K1, oh * K1, K1
+        d.kw_taps, d.run, d.stride = 1, K1, 1
+        d.ldc, d.relu = N, 1
+        d.in2, d.K2, d.stride2 = x.data_ptr(), K2, st
+        d.in2_img_stride, d.in2_row_stride, d.in2_pix_stride = h * h * K2, h * K2, K2
+        us = run(d)
+        fl = 2.0 * M * N * (K1 + K2)
+        by = 2.0 * (M * K1 + M * K2 + M * N)
+        print(f"s{si} tail M={M:8d} N={N:5d} K={K1}+{K2} {us:8.1f} us {fl / us / 1e6:7.1f} TF  ~{by / us / 1e6:5.2f} TB/s")
+        cin, h = 4 * wd, oh
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tail":
+    tails()
+    sys.exit(0)
