@@ -205,11 +205,15 @@ __device__ __forceinline__ void merge_row_stats(const LnRef& l, int m, float& me
     rstd = 1.0f / sqrtf(m2 / n + 1e-5f);
 }
 
-template <typename T, int MT>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
-    constexpr int VEC = 16 / (int)sizeof(T), EPR = 4 * VEC, TPW = 2, U = MT >= 4 ? 2 : 4, ROWS = MT * 16;
+// NWV waves share the 128 columns (8 / NWV tiles of 16 each).  A wave's weight stream is a chain of
+// round trips to L2 with 8 fragment loads in flight, so eight waves of one tile each finish it in half
+// the round trips of four waves of two.
+template <typename T, int MT, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const SkinnyArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T), EPR = 4 * VEC, TPW = 8 / NWV, U = (MT >= 4 ? 4 : 8) / TPW, ROWS = MT * 16;
+    constexpr int NT = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
-    __shared__ float rs_x[ROWS][2], rs_r[ROWS][2], red[2][4][ROWS];
+    __shared__ float rs_x[ROWS][2], rs_r[ROWS][2], red[2][NWV][ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int cb = blockIdx.x % a.col_blocks, rb = blockIdx.x / a.col_blocks;
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
     const T* wp = (const T*)a.w + ((long long)(nb / 16) * nk * 64 + lane) * VEC;
     uint4 wa[U][TPW], wb[U][TPW];
     auto load_w = [&](int kt0, uint4 (&wf)[U][TPW]) {
+        if (kt0 >= nk) return;  // nothing left to prefetch (wave-uniform)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kt = kt0 + u < nk ? kt0 + u : nk - 1;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
     if (a.xl.raw) __syncthreads();
     {
         const int cpr = a.K / VEC;
-        for (int c = tid; c < ROWS * cpr; c += 256) {
+        for (int c = tid; c < ROWS * cpr; c += NT) {
             const int row = c / cpr, ch = c - row * cpr;
             const int mr = m0 + row < a.M ? m0 + row : a.M - 1;
             if (a.xl.raw) {
@@ -344,7 +349,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = i * 16 + r;
-            const float mean = ((red[0][0][row] + red[0][1][row]) + (red[0][2][row] + red[0][3][row])) / cnt;
+            float rsum = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < NWV; ++w8) rsum += red[0][w8][row];
+            const float mean = rsum / cnt;
             float sq = 0.f;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
@@ -361,8 +369,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
         }
         __syncthreads();
         if (tid < ROWS && m0 + tid < a.M) {
-            const float mean = ((red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid])) / cnt;
-            const float m2 = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+            float rsum = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < NWV; ++w8) { rsum += red[0][w8][tid]; m2 += red[1][w8][tid]; }
+            const float mean = rsum / cnt;
             float* dst = a.stats_out + ((long long)(m0 + tid) * a.col_blocks + cb) * 2;
             dst[0] = mean;
             dst[1] = m2;
@@ -399,20 +409,20 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
     }
 }
 
-template <typename T, int MT> int launch_skinny(SkinnyArgs& a, hipStream_t s) {
+template <typename T, int MT, int NWV = 4> int launch_skinny(SkinnyArgs& a, hipStream_t s) {
     const size_t lds = (size_t)MT * 16 * ((size_t)a.K * sizeof(T) + 16);
     MIC_ARG_CHECK(lds <= 140 * 1024, "mic_linear_skinny: K=%d needs %zu bytes of LDS", a.K, lds);
     if (lds > 48 * 1024) {
         static bool granted = false;
         if (!granted) {
-            MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<T, MT>),
+            MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<T, MT, NWV>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
             granted = true;
         }
     }
     a.col_blocks = (a.N + 127) / 128;
     const int grid = a.col_blocks * ((a.M + MT * 16 - 1) / (MT * 16));
-    MIC_LAUNCH((skinny_gemm_kernel<T, MT>), dim3(grid), dim3(256), lds, s, a);
+    MIC_LAUNCH((skinny_gemm_kernel<T, MT, NWV>), dim3(grid), dim3(64 * NWV), lds, s, a);
     return 0;
 }
 
@@ -507,6 +517,13 @@ extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) {
     const long long cbs = (d->N + 127) / 128;
     int mt = cbs * ((d->M + 31) / 32) >= 512 ? 2 : 1;  // measured: 64-row blocks never win at these sizes
     if (forced_mt) mt = forced_mt;
+    static const int forced_nw = [] { const char* e = getenv("MIC_SKINNY_NW"); return e ? atoi(e) : 0; }();
+    int nw = mt <= 2 ? 8 : 4;  // measured inside the captured decode step: eight waves win at every shape
+    if (forced_nw) nw = forced_nw;
+    if (nw == 8 && mt <= 2) {
+        if (mt == 2) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 2, 8>(a, s) : launch_skinny<float, 2, 8>(a, s);
+        return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 1, 8>(a, s) : launch_skinny<float, 1, 8>(a, s);
+    }
     if (mt == 4) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 4>(a, s) : launch_skinny<float, 4>(a, s);
     if (mt == 2) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 2>(a, s) : launch_skinny<float, 2>(a, s);
     return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 1>(a, s) : launch_skinny<float, 1>(a, s);
