@@ -436,6 +436,157 @@ __global__ __launch_bounds__(256) void cross_attn_image_kernel(const AttnArgs a)
     }
 }
 
+// Cross-attention for all beams of one image by a workgroup of 16 waves, for H == 64 chunks of 16
+// bytes (one wave-instruction = one whole key or value row, 1 KiB, fully coalesced) and S <= 64.
+// Every key and value row of the image is requested once, up front, by the wave that owns the
+// position (p = wave + 16 i), so the launch pays ONE memory round trip; scores, softmax and the
+// weighted sum then run on registers and LDS, and each row is used for every beam.  Beams are taken
+// in groups of RG to bound registers.
+template <typename T, int RG>
+__global__ __launch_bounds__(1024) void cross_attn_wide_kernel(const AttnArgs a) {
+    constexpr int VEC = Vec16<T>::N, NI = 4, SP = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, heads = a.heads, S = a.S, R = a.rows_per_image;
+    const int lph = 64 / heads;  // lanes per head
+    float* sc = smem;                       // [RG][heads][SP]
+    float* part = smem + RG * heads * SP;   // [8][RG][H]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, n0 = b * R, h = lane / lph;
+    const float scale = sqrtf(1.0f / (float)(H / heads));
+    const T* kvb = (const T*)a.kv + (long long)b * S * 2 * H + lane * VEC;
+    Vec16<T> kreg[NI], vreg[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int p = wave + 16 * i;
+        if (p < S) {
+            kreg[i] = ld16(kvb + (long long)p * 2 * H);
+            vreg[i] = ld16(kvb + (long long)p * 2 * H + H);
+        }
+    }
+    for (int r0 = 0; r0 < R; r0 += RG) {
+        const int rn = R - r0 < RG ? R - r0 : RG;
+        float q[RG][VEC];
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const float* qp = a.q + (long long)(n0 + r0 + (rr < rn ? rr : 0)) * a.ldq + lane * VEC;
+#pragma unroll
+            for (int e4 = 0; e4 < VEC; e4 += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(qp + e4);
+                q[rr][e4] = v.x * scale; q[rr][e4 + 1] = v.y * scale; q[rr][e4 + 2] = v.z * scale; q[rr][e4 + 3] = v.w * scale;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = wave + 16 * i;
+            if (p < S) {
+                float kf[VEC], sum[RG];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) kf[e] = to_f32<T>(kreg[i].v[e]);
+#pragma unroll
+                for (int rr = 0; rr < RG; ++rr) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v = fmaf(q[rr][e], kf[e], v);
+                    for (int o = lph >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    sum[rr] = v;
+                }
+                if ((lane & (lph - 1)) == 0) {
+#pragma unroll
+                    for (int rr = 0; rr < RG; ++rr)
+                        if (rr < rn) sc[(rr * heads + h) * SP + p] = sum[rr];
+                }
+            }
+        }
+        __syncthreads();
+        for (int rh = wave; rh < rn * heads; rh += 16) {  // softmax of one (beam, head) per wave, lane = position
+            float* row = sc + rh * SP;
+            const float v = lane < S ? row[lane] : -INFINITY;
+            const float m = wave_max(v);
+            const float e = lane < S ? expf(v - m) : 0.f;
+            const float tot = wave_sum(e);
+            if (lane < S) row[lane] = e / tot;
+        }
+        __syncthreads();
+        if (a.attn_out) {
+            const float hs = a.attn_scale / (float)heads;
+            for (int i = tid; i < rn * S; i += 1024) {
+                const int rr = i / S, p = i - rr * S;
+                float sum = 0.f;
+                for (int hh = 0; hh < heads; ++hh) sum += sc[(rr * heads + hh) * SP + p];
+                float* dst = a.attn_out + (long long)(n0 + r0 + rr) * a.ld_attn + p;
+                *dst = (a.accumulate ? *dst : 0.f) + sum * hs;
+            }
+        }
+        float acc[RG][VEC];
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[rr][e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = wave + 16 * i;
+            if (p < S) {
+                float vf[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) vf[e] = to_f32<T>(vreg[i].v[e]);
+#pragma unroll
+                for (int rr = 0; rr < RG; ++rr) {
+                    const float wgt = rr < rn ? sc[(rr * heads + h) * SP + p] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[rr][e] = fmaf(wgt, vf[e], acc[rr][e]);
+                }
+            }
+        }
+        // 16 partial sums per output: waves 8..15 hand theirs to waves 0..7, which publish the pair sums
+        float* mine = part + ((wave & 7) * RG) * H + lane * VEC;
+        if (wave >= 8) {
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr)
+#pragma unroll
+                for (int e4 = 0; e4 < VEC; e4 += 4)
+                    *reinterpret_cast<float4*>(mine + rr * H + e4) = make_float4(acc[rr][e4], acc[rr][e4 + 1], acc[rr][e4 + 2], acc[rr][e4 + 3]);
+        }
+        __syncthreads();
+        if (wave < 8) {
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr)
+#pragma unroll
+                for (int e4 = 0; e4 < VEC; e4 += 4) {
+                    const float4 o = *reinterpret_cast<const float4*>(mine + rr * H + e4);
+                    *reinterpret_cast<float4*>(mine + rr * H + e4) =
+                        make_float4(acc[rr][e4] + o.x, acc[rr][e4 + 1] + o.y, acc[rr][e4 + 2] + o.z, acc[rr][e4 + 3] + o.w);
+                }
+        }
+        __syncthreads();
+        for (int i = tid; i < rn * H; i += 1024) {
+            const int rr = i / H, col = i - rr * H;
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) sum += part[(g * RG + rr) * H + col];
+            ((T*)a.o)[(long long)(n0 + r0 + rr) * a.ld_o + col] = from_f32<T>(sum);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int RG> int launch_cross_wide_rg(const AttnArgs& a, hipStream_t s) {
+    const size_t lds = sizeof(float) * (RG * (size_t)a.heads * 64 + 8 * RG * (size_t)a.H);
+    static bool granted = false;
+    if (!granted) {
+        MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_wide_kernel<T, RG>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        granted = true;
+    }
+    MIC_LAUNCH((cross_attn_wide_kernel<T, RG>), dim3(a.N / a.rows_per_image), dim3(1024), lds, s, a);
+    return 0;
+}
+template <typename T> int launch_cross_wide(const AttnArgs& a, hipStream_t s) {
+    const int R = a.rows_per_image;  // group size: few idle slots in the last group, at most 4 beams in registers
+    if (R == 2) return launch_cross_wide_rg<T, 2>(a, s);
+    if (R % 4 == 0 || R == 7) return launch_cross_wide_rg<T, 4>(a, s);
+    return launch_cross_wide_rg<T, 3>(a, s);
+}
+
 template <typename T> int launch_cross_image(const AttnArgs& a, hipStream_t s, size_t lds) {
     constexpr int VEC = Vec16<T>::N;
     const int cpl = (a.H / a.heads / VEC + 15) / 16;
@@ -569,6 +720,15 @@ extern "C" int mic_cross_attn_step(const float* q, int ldq, const void* kv, int 
     hipStream_t s = (hipStream_t)stream;
     // One workgroup per image reads each key/value row once for all beams, but measured slower than
     // one workgroup per row on MI355X (25 us vs 20 us at 768 rows, S=49, H=512): kept as an opt-in.
+    {
+        // wide form: one workgroup of 16 waves per image, every key/value row fetched once for all beams
+        static const bool no_wide = getenv("MIC_CROSS_NO_WIDE") != nullptr;
+        const int vec = 16 / (int)mic_dtype_size(dtype);
+        const size_t lds = sizeof(float) * (4 * (size_t)heads * 64 + 8 * 4 * (size_t)H);
+        if (!no_wide && H == 64 * vec && S <= 64 && heads <= 64 && (heads & (heads - 1)) == 0 && rows_per_image >= 2 &&
+            N % rows_per_image == 0 && ldq % 4 == 0 && ((uintptr_t)q & 15) == 0 && lds <= 150 * 1024)
+            return dtype == MIC_BF16 ? launch_cross_wide<bf16_t>(a, s) : launch_cross_wide<float>(a, s);
+    }
     static const bool per_image = getenv("MIC_CROSS_PER_IMAGE") != nullptr;
     if (per_image && rows_per_image > 1 && rows_per_image <= MAXR && N % rows_per_image == 0) {
         // one workgroup per image when its beams' queries, scores and partial outputs fit in 64 KiB of LDS

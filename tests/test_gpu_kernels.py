@@ -287,6 +287,35 @@ def test_attention_steps(L, dtype, H, heads):
     np.testing.assert_allclose(attn.cpu().numpy(), 0.25 + 0.5 * wref.numpy(), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype,H,heads", [(torch.bfloat16, 512, 2), (torch.bfloat16, 512, 8), (torch.float32, 256, 4)])
+@pytest.mark.parametrize("rpi,S", [(2, 49), (3, 64), (4, 17), (5, 49), (7, 49), (8, 33)])
+def test_cross_attention_one_workgroup_per_image(L, dtype, H, heads, rpi, S):
+    """Shapes that take the 16-wave per-image kernel (hidden size = 64 sixteen-byte chunks, S <= 64): every
+    beam count, a full and a ragged last key group, with and without the attention-weight output."""
+    g = torch.Generator().manual_seed(H + heads + rpi + S)
+    B, hd, code = 5, H // heads, L.dtype_code(dtype)
+    N = B * rpi
+    kv = torch.randn(B, S, 2 * H, generator=g)
+    if dtype == torch.bfloat16:
+        kv = kv.bfloat16().float()
+    q = torch.randn(N, H, generator=g)
+    qd, kvd = q.to(DEV), kv.to(DEV, dtype)
+    o = torch.empty(N, H, dtype=dtype, device=DEV)
+    attn = torch.full((N, S), 7.0, device=DEV)
+    L.check(L.lib.mic_cross_attn_step(qd.data_ptr(), H, kvd.data_ptr(), S, rpi, o.data_ptr(), H, attn.data_ptr(), S,
+                                      1.0, 0, code, N, H, heads, L.stream_ptr()))
+    qh = (q * math.sqrt(1.0 / hd)).view(B, rpi, heads, hd)
+    k_, v_ = kv[:, :, :H].view(B, S, heads, hd), kv[:, :, H:].view(B, S, heads, hd)
+    w = torch.softmax(torch.einsum("brhd,bshd->brhs", qh, k_), dim=-1)
+    ref = torch.einsum("brhs,bshd->brhd", w, v_).reshape(N, H)
+    np.testing.assert_allclose(o.float().cpu().numpy(), ref.numpy(), **_tol(dtype))
+    np.testing.assert_allclose(attn.cpu().numpy(), w.mean(dim=2).reshape(N, S).numpy(), rtol=1e-4, atol=1e-6)
+    o2 = torch.empty(N, H, dtype=dtype, device=DEV)
+    L.check(L.lib.mic_cross_attn_step(qd.data_ptr(), H, kvd.data_ptr(), S, rpi, o2.data_ptr(), H, None, 0,
+                                      1.0, 0, code, N, H, heads, L.stream_ptr()))
+    assert torch.equal(o, o2)
+
+
 @pytest.mark.parametrize("V", [200, 3500, 4096, 4097, 6501])
 @pytest.mark.parametrize("K", [1, 3, 5, 8])
 def test_logsoftmax_topk(L, V, K):
