@@ -274,6 +274,88 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const AttnArgs a) {
     }
 }
 
+// Self-attention step for H == 64 chunks of 16 bytes and at most 32 cached positions: wave w owns
+// positions w, w+4, ...; a key / value row is one fully coalesced 1 KiB wave-instruction, and every row
+// of the prefix is requested up front (ancestry index, then the row: two dependent round trips for
+// the whole launch, no barrier in front of them).
+template <typename T>
+__global__ __launch_bounds__(256) void self_attn_wide_kernel(const AttnArgs a) {
+    constexpr int VEC = Vec16<T>::N, NI = 8, SP = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, heads = a.heads, t = a.t, P = t + 1;
+    const int lph = 64 / heads;
+    float* sc = smem;                 // [heads][SP]
+    float* part = smem + heads * SP;  // [4][H]
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane / lph;
+    const float scale = sqrtf(1.0f / (float)(H / heads));
+    const float* qrow = a.q + (long long)n * a.ldq + lane * VEC;
+    Vec16<T> knew, vnew;  // position t: the fresh projection rounded through T, as the cache will hold it
+    float q[VEC];
+#pragma unroll
+    for (int e4 = 0; e4 < VEC; e4 += 4) {
+        const float4 qv = *reinterpret_cast<const float4*>(qrow + e4);
+        const float4 kv = *reinterpret_cast<const float4*>(qrow + H + e4);
+        const float4 vv = *reinterpret_cast<const float4*>(qrow + 2 * H + e4);
+        q[e4] = qv.x * scale; q[e4 + 1] = qv.y * scale; q[e4 + 2] = qv.z * scale; q[e4 + 3] = qv.w * scale;
+        knew.v[e4] = from_f32<T>(kv.x); knew.v[e4 + 1] = from_f32<T>(kv.y); knew.v[e4 + 2] = from_f32<T>(kv.z); knew.v[e4 + 3] = from_f32<T>(kv.w);
+        vnew.v[e4] = from_f32<T>(vv.x); vnew.v[e4 + 1] = from_f32<T>(vv.y); vnew.v[e4 + 2] = from_f32<T>(vv.z); vnew.v[e4 + 3] = from_f32<T>(vv.w);
+    }
+    Vec16<T> kreg[NI], vreg[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int p = wave + 4 * i;
+        if (p < t) {
+            const long long src = a.anc ? a.anc[(long long)n * a.t_cap + p] : n;
+            kreg[i] = ld16((const T*)a.kcache + (src * a.t_cap + p) * H + lane * VEC);
+            vreg[i] = ld16((const T*)a.vcache + (src * a.t_cap + p) * H + lane * VEC);
+        } else if (p == t) {
+            kreg[i] = knew;
+            vreg[i] = vnew;
+            st16((T*)a.kcache + ((long long)n * a.t_cap + t) * H + lane * VEC, knew);
+            st16((T*)a.vcache + ((long long)n * a.t_cap + t) * H + lane * VEC, vnew);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int p = wave + 4 * i;
+        if (p < P) {
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v = fmaf(q[e], to_f32<T>(kreg[i].v[e]), v);
+            for (int o = lph >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((lane & (lph - 1)) == 0) sc[h * SP + p] = v;
+        }
+    }
+    __syncthreads();
+    for (int hh = wave; hh < heads; hh += 4) {
+        float* row = sc + hh * SP;
+        const float v = lane < P ? row[lane] : -INFINITY;
+        const float m = wave_max(v);
+        const float e = lane < P ? expf(v - m) : 0.f;
+        const float tot = wave_sum(e);
+        if (lane < P) row[lane] = e / tot;
+    }
+    __syncthreads();
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int p = wave + 4 * i;
+        if (p < P) {
+            const float wgt = sc[h * SP + p];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, to_f32<T>(vreg[i].v[e]), acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e4 = 0; e4 < VEC; e4 += 4)
+        *reinterpret_cast<float4*>(part + wave * H + lane * VEC + e4) = make_float4(acc[e4], acc[e4 + 1], acc[e4 + 2], acc[e4 + 3]);
+    __syncthreads();
+    T* orow = (T*)a.o + (long long)n * a.ld_o;
+    for (int i = tid; i < H; i += 256) orow[i] = from_f32<T>((part[i] + part[H + i]) + (part[2 * H + i] + part[3 * H + i]));
+}
+
 // Cross-attention for all rows of one image in one workgroup: the beams of an image attend to the
 // same S keys/values, so each key / value row is loaded once and used for every beam (the per-row
 // form re-reads 2*S*H elements per beam from L2, which is what bounds it).
@@ -703,6 +785,17 @@ extern "C" int mic_self_attn_step(const float* qkv, void* kcache, void* vcache, 
     a.q = qkv; a.ldq = 3 * H; a.kcache = kcache; a.vcache = vcache; a.anc = anc; a.t = t; a.t_cap = t_cap;
     a.o = o; a.ld_o = ld_o; a.N = N; a.H = H; a.heads = heads;
     hipStream_t s = (hipStream_t)stream;
+    {
+        static const bool no_wide = getenv("MIC_SELF_NO_WIDE") != nullptr;
+        const int vec = 16 / (int)mic_dtype_size(dtype);
+        if (!no_wide && H == 64 * vec && t_cap <= 32 && heads <= 64 && (heads & (heads - 1)) == 0 && ((uintptr_t)qkv & 15) == 0 &&
+            ((uintptr_t)kcache & 15) == 0 && ((uintptr_t)vcache & 15) == 0) {
+            const size_t lds = sizeof(float) * ((size_t)heads * 32 + 4 * (size_t)H);
+            if (dtype == MIC_BF16) MIC_LAUNCH(self_attn_wide_kernel<bf16_t>, dim3(N), dim3(256), lds, s, a);
+            else MIC_LAUNCH(self_attn_wide_kernel<float>, dim3(N), dim3(256), lds, s, a);
+            return 0;
+        }
+    }
     return dtype == MIC_BF16 ? launch_attn<bf16_t, true>(a, s) : launch_attn<float, true>(a, s);
 }
 

@@ -231,12 +231,12 @@ def test_embed_layernorm_lstm_cell_gather(L):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("H,heads", [(64, 2), (512, 2), (256, 8), (512, 1)])
-def test_attention_steps(L, dtype, H, heads):
+@pytest.mark.parametrize("H,heads,Tc", [(64, 2, 9), (512, 2, 9), (256, 8, 9), (512, 1, 9), (512, 2, 32), (512, 8, 33), (256, 4, 32)])
+def test_attention_steps(L, dtype, H, heads, Tc):
     """Self form against a cache filled step by step with a random ancestry; cross form against
     per-image K/V; both versus softmax(q k^T / sqrt(hd)) v computed on the CPU."""
     g = torch.Generator().manual_seed(H + heads)
-    N, Tc, S, rpi = 6, 9, 49, 3
+    N, S, rpi = 6, 49, 3
     hd = H // heads
     code = L.dtype_code(dtype)
 
