@@ -518,7 +518,9 @@ extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) {
     int mt = cbs * ((d->M + 31) / 32) >= 512 ? 2 : 1;  // measured: 64-row blocks never win at these sizes
     if (forced_mt) mt = forced_mt;
     static const int forced_nw = [] { const char* e = getenv("MIC_SKINNY_NW"); return e ? atoi(e) : 0; }();
-    int nw = mt <= 2 ? 8 : 4;  // measured inside the captured decode step: eight waves win at every shape
+    // measured inside the captured decode step: eight waves win for 16-row blocks; the 32-row blocks of
+    // the vocabulary projection need their three workgroups per CU and keep four
+    int nw = mt == 1 ? 8 : 4;
     if (forced_nw) nw = forced_nw;
     if (nw == 8 && mt <= 2) {
         if (mt == 2) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 2, 8>(a, s) : launch_skinny<float, 2, 8>(a, s);
