@@ -95,3 +95,38 @@ def test_shard_range_covers_everything_once():
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= (n + world - 1) // world
     with pytest.raises(ValueError):
         D.shard_range(10, 2, 2)
+
+
+def test_checkpoint_loader_follows_the_reference_factory(tmp_path):
+    """A file shaped like train.save_checkpoint's (train.py:390-403) comes back as the model class the
+    reference's factory (runner/runner.py:263-288) would build; nothing needs a GPU until .to()."""
+    import torch
+    import image_captioning_amd as amd
+    vocab = amd.Vocabulary.synthetic(50)
+    sd = amd.weights.random_transformer_state(50, 32, 2, 12, seed=0)
+    cfg = {"model": "transformer", "encoder": "resnet50", "num_heads": 4, "hidden_size": 32, "num_layers": 2}
+    path = tmp_path / "BEST.pt"
+    torch.save({"epoch": 3, "model_state": sd, "optimizer_state": {"state": {}, "param_groups": []}, "scheduler_state": None,
+                "best_val_loss": 1.5, "train_loss": 1.2, "epochs_no_improve": 0, "lr": (1e-4, 1e-3), "config": cfg, "use_rl": False}, path)
+    import pytest
+    with pytest.raises(KeyError, match="ResNet-50"):  # config says resnet50, the file has no encoder weights
+        amd.checkpoint.load_checkpoint(str(path), vocab)
+    sd.update(amd.weights.random_swin_state(0, 32, (1, 1, 1, 1), (1, 2, 4, 8)))
+    sd.update(amd.weights.random_head_state("swin", 32, 0, in_dim=256))
+    cfg["encoder"] = "swin"
+    torch.save({"model_state": sd, "config": cfg}, path)
+    model, config = amd.checkpoint.load_checkpoint(str(path), vocab, torch.float32)
+    assert isinstance(model, amd.transformer.ImageCaptioner) and model.encoder_kind == "swin" and model.num_heads == 4
+    assert config["model"] == "transformer" and model.max_len == 12
+    lsd = amd.weights.random_lstm_state("intermediate", 50, 16, 24, 2)
+    lsd.update(amd.weights.random_resnet50_state(0))
+    lsd.update(amd.weights.random_head_state("intermediate", 16, 0))
+    torch.save({"model_state": lsd, "config": {"model": "intermediate", "encoder": "resnet50"}}, path)
+    model, _ = amd.checkpoint.load_checkpoint(str(path), vocab)
+    assert isinstance(model, amd.lstm.IntermediateImageCaptioner)
+    torch.save({"model_state": lsd, "config": {"model": "intermediate", "encoder": "swin"}}, path)
+    with pytest.raises(ValueError, match="swin"):
+        amd.checkpoint.load_checkpoint(str(path), vocab)
+    torch.save({"weights": lsd}, path)
+    with pytest.raises(ValueError, match="not a checkpoint"):
+        amd.checkpoint.load_checkpoint(str(path), vocab)
