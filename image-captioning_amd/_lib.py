@@ -81,8 +81,12 @@ _TR_B = ["self_in_b", "self_out_b", "cross_q_b", "cross_kv_b", "cross_out_b", "f
 _TR_LN = ["ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b"]
 
 
+FOLD_MAX_HEADS = 2
+
+
 class TrLayer(C.Structure):
-    _fields_ = [(n, vp) for n in _TR_W + _TR_B + _TR_LN + ["self_out_wf", "cross_out_wf", "ff2_wf", "self_in_wf", "cross_q_wf", "ff1_wf"]]
+    _fields_ = ([(n, vp) for n in _TR_W + _TR_B + _TR_LN + ["self_out_wf", "cross_out_wf", "ff2_wf", "self_in_wf", "cross_q_wf", "ff1_wf"]]
+                + [("cross_kf_w", vp * FOLD_MAX_HEADS), ("cross_vf_w", vp * FOLD_MAX_HEADS), ("cross_qb_scaled", vp)])
 
 
 class TrDecoder(C.Structure):
@@ -94,7 +98,8 @@ class TrWorkspace(C.Structure):
     _fields_ = [("N", i32), ("t_cap", i32), ("S", i32), ("rows_per_image", i32),
                 ("x", vp), ("xt", vp), ("y", vp), ("qkv", vp), ("o", vp), ("ffh", vp), ("logits", vp),
                 ("kcache", vp * MAX_LAYERS), ("vcache", vp * MAX_LAYERS), ("cross_kv", vp * MAX_LAYERS),
-                ("attn", vp), ("top_val", vp), ("top_idx", vp), ("stats", vp * 2)]
+                ("attn", vp), ("top_val", vp), ("top_idx", vp), ("stats", vp * 2),
+                ("cross_kf", vp * MAX_LAYERS), ("cross_vf", vp * MAX_LAYERS), ("cross_c", vp * MAX_LAYERS)]
 
 
 class LstmDecoder(C.Structure):
@@ -134,6 +139,10 @@ SIGNATURES = {
     "mic_self_attn_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_cross_attn_step": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, f32, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_cross_attn_folded_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mic_cross_attn_folded": (C.c_int, [P(LnRef), vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, f32, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, vp]),
+    "mic_cross_fold_bias": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_lstm_cell": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_gather_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "mic_logsoftmax_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, vp, vp, vp, vp]),

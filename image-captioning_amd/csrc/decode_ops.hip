@@ -651,6 +651,258 @@ __global__ __launch_bounds__(1024) void cross_attn_wide_kernel(const AttnArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Whole cross-attention sub-layer of a post-LN decoder layer in one launch, for few heads:
+//     y = LN(r) + sum_h softmax_s( LN(r) . K'_h[s] + c_h[s] ) V'_h[s] + b_o          (+ row statistics of y)
+// with the query projection folded into the per-image keys, K'_h[s] = W_q,h^T k_h[s] / sqrt(d) and
+// c_h[s] = b_q,h . k_h[s] / sqrt(d), and the output projection folded into the values,
+// V'_h[s] = W_o[:, h] v_h[s]; both are computed once per image next to the K/V projection.  The two
+// projection GEMMs of the sub-layer and their launches disappear; the price is H instead of H/heads
+// elements per (position, head) of K' and V'.  Same decomposition as cross_attn_wide_kernel: 16 waves per
+// image, wave w owns positions w, w+16, ..., every K' row requested up front, V' rows as soon as the
+// scores are out (in flight during the softmax).
+struct FoldArgs {
+    const float* raw;      // [N][ld] pre-LayerNorm stream r (y may alias it)
+    const float* stats;    // [N][parts][2]
+    const float *gamma, *beta;
+    int ld, parts;
+    const void *kf, *vf;   // [B][S][heads][H]
+    const float* c;        // [B][S][heads]
+    const float* bo;       // [H]
+    float* y;              // [N][H]
+    float* stats_out;      // [N][parts][2]
+    float* attn_out;
+    int ld_attn;
+    float attn_scale;
+    int accumulate, S, R, N, H;
+};
+
+// MULTI: more beams than one register group; the K' rows are then re-requested per group (they come from L2
+// after the first) so that K' and V' never have to be held in registers together.
+template <typename T, int RG, int HEADS, bool MULTI>
+__global__ __launch_bounds__(1024) void cross_fold_kernel(const FoldArgs a) {
+    constexpr int VEC = Vec16<T>::N, NI = 4, SP = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, S = a.S, R = a.R;
+    float* xs = smem;                           // [R][H] LayerNorm(r)
+    float* sc = xs + R * H;                     // [RG][HEADS][SP]
+    float* part = sc + RG * HEADS * SP;         // [8][RG][H]
+    float* rstat = part + 8 * RG * H;           // [R][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, n0 = b * R;
+    const T* kfb = (const T*)a.kf + (long long)b * S * HEADS * H + lane * VEC;
+    const T* vfb = (const T*)a.vf + (long long)b * S * HEADS * H + lane * VEC;
+    Vec16<T> kreg[NI][HEADS];
+    auto load_keys = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = wave + 16 * i;
+            if (p < S) {
+#pragma unroll
+                for (int h = 0; h < HEADS; ++h) kreg[i][h] = ld16(kfb + ((long long)p * HEADS + h) * H);
+            }
+        }
+    };
+    if (!MULTI) load_keys();  // in flight during the LayerNorm prologue
+    if (tid < R) {  // mean and 1/sqrt(var + eps) of row tid from its per-part (mean, M2) pairs
+        const float* st = a.stats + (long long)(n0 + tid) * a.parts * 2;
+        float n = 0.f, mu = 0.f, m2 = 0.f;
+        for (int p = 0; p < a.parts; ++p) {
+            const float nb = (float)min(128, H - 128 * p), mb = st[2 * p], sb = st[2 * p + 1];
+            const float nt = n + nb, d = mb - mu;
+            mu += d * (nb / nt);
+            m2 += sb + d * d * (n * nb / nt);
+            n = nt;
+        }
+        rstat[2 * tid] = mu;
+        rstat[2 * tid + 1] = 1.0f / sqrtf(m2 / n + 1e-5f);
+    }
+    __syncthreads();
+    for (int i = tid; i < R * (H / 4); i += 1024) {
+        const int r = i / (H / 4), c4 = (i - r * (H / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(a.raw + (long long)(n0 + r) * a.ld + c4);
+        const float4 g = *reinterpret_cast<const float4*>(a.gamma + c4), be = *reinterpret_cast<const float4*>(a.beta + c4);
+        const float mean = rstat[2 * r], rstd = rstat[2 * r + 1];
+        *reinterpret_cast<float4*>(xs + r * H + c4) = make_float4((v.x - mean) * rstd * g.x + be.x, (v.y - mean) * rstd * g.y + be.y,
+                                                                  (v.z - mean) * rstd * g.z + be.z, (v.w - mean) * rstd * g.w + be.w);
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < (MULTI ? R : 1); r0 += RG) {
+        const int rn = R - r0 < RG ? R - r0 : RG;
+        if (MULTI) load_keys();
+        float q[RG][VEC];
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const float* qp = xs + (r0 + (rr < rn ? rr : 0)) * H + lane * VEC;
+#pragma unroll
+            for (int e4 = 0; e4 < VEC; e4 += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(qp + e4);
+                q[rr][e4] = v.x; q[rr][e4 + 1] = v.y; q[rr][e4 + 2] = v.z; q[rr][e4 + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = wave + 16 * i;
+            if (p < S) {
+#pragma unroll
+                for (int h = 0; h < HEADS; ++h) {
+                    float kf[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) kf[e] = to_f32<T>(kreg[i][h].v[e]);
+                    const float cc = a.c[((long long)b * S + p) * HEADS + h];
+#pragma unroll
+                    for (int rr = 0; rr < RG; ++rr) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v = fmaf(q[rr][e], kf[e], v);
+                        v = wave_sum(v);
+                        if (lane == 0 && rr < rn) sc[(rr * HEADS + h) * SP + p] = v + cc;
+                    }
+                }
+            }
+        }
+        // value rows: requested now, consumed after the softmax
+        Vec16<T> vreg[NI][HEADS];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = wave + 16 * i;
+            if (p < S) {
+#pragma unroll
+                for (int h = 0; h < HEADS; ++h) vreg[i][h] = ld16(vfb + ((long long)p * HEADS + h) * H);
+            }
+        }
+        __syncthreads();
+        for (int rh = wave; rh < rn * HEADS; rh += 16) {
+            float* row = sc + rh * SP;
+            const float v = lane < S ? row[lane] : -INFINITY;
+            const float m = wave_max(v);
+            const float e = lane < S ? expf(v - m) : 0.f;
+            const float tot = wave_sum(e);
+            if (lane < S) row[lane] = e / tot;
+        }
+        __syncthreads();
+        if (a.attn_out) {
+            const float hs = a.attn_scale / (float)HEADS;
+            for (int i = tid; i < rn * S; i += 1024) {
+                const int rr = i / S, p = i - rr * S;
+                float sum = 0.f;
+#pragma unroll
+                for (int hh = 0; hh < HEADS; ++hh) sum += sc[(rr * HEADS + hh) * SP + p];
+                float* dst = a.attn_out + (long long)(n0 + r0 + rr) * a.ld_attn + p;
+                *dst = (a.accumulate ? *dst : 0.f) + sum * hs;
+            }
+        }
+        float acc[RG][VEC];
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[rr][e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = wave + 16 * i;
+            if (p < S) {
+#pragma unroll
+                for (int h = 0; h < HEADS; ++h) {
+                    float vf[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) vf[e] = to_f32<T>(vreg[i][h].v[e]);
+#pragma unroll
+                    for (int rr = 0; rr < RG; ++rr) {
+                        const float wgt = rr < rn ? sc[(rr * HEADS + h) * SP + p] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[rr][e] = fmaf(wgt, vf[e], acc[rr][e]);
+                    }
+                }
+            }
+        }
+        float* mine = part + ((wave & 7) * RG) * H + lane * VEC;
+        if (wave >= 8) {
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr)
+#pragma unroll
+                for (int e4 = 0; e4 < VEC; e4 += 4)
+                    *reinterpret_cast<float4*>(mine + rr * H + e4) = make_float4(acc[rr][e4], acc[rr][e4 + 1], acc[rr][e4 + 2], acc[rr][e4 + 3]);
+        }
+        __syncthreads();
+        if (wave < 8) {
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr)
+#pragma unroll
+                for (int e4 = 0; e4 < VEC; e4 += 4) {
+                    const float4 o = *reinterpret_cast<const float4*>(mine + rr * H + e4);
+                    *reinterpret_cast<float4*>(mine + rr * H + e4) =
+                        make_float4(acc[rr][e4] + o.x, acc[rr][e4 + 1] + o.y, acc[rr][e4 + 2] + o.z, acc[rr][e4 + 3] + o.w);
+                }
+        }
+        __syncthreads();
+        // y = attention + b_o + LN(r), and its statistics per 128 columns: one wave per (row, part), 2 columns per lane
+        for (int pair = wave; pair < rn * a.parts; pair += 16) {
+            const int rr = pair / a.parts, pp = pair - rr * a.parts;
+            const int col = pp * 128 + lane * 2;
+            const bool ok = col < H;  // H is a multiple of 4, so both columns or none
+            float v0 = 0.f, v1 = 0.f;
+            if (ok) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float2 t = *reinterpret_cast<const float2*>(part + (g * RG + rr) * H + col);
+                    v0 += t.x; v1 += t.y;
+                }
+                v0 += a.bo[col] + xs[(r0 + rr) * H + col];
+                v1 += a.bo[col + 1] + xs[(r0 + rr) * H + col + 1];
+                *reinterpret_cast<float2*>(a.y + (long long)(n0 + r0 + rr) * H + col) = make_float2(v0, v1);
+            }
+            const float cnt = (float)min(128, H - 128 * pp);
+            const float mean = wave_sum(ok ? v0 + v1 : 0.f) / cnt;
+            const float d0 = ok ? v0 - mean : 0.f, d1 = ok ? v1 - mean : 0.f;
+            const float m2 = wave_sum(d0 * d0 + d1 * d1);
+            if (lane == 0 && a.stats_out) {
+                float* dst = a.stats_out + ((long long)(n0 + r0 + rr) * a.parts + pp) * 2;
+                dst[0] = mean;
+                dst[1] = m2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// c[row][h] = qb[h*hd ..] . k[row][h*hd ..]: one wave per (key row, head)
+template <typename T>
+__global__ __launch_bounds__(256) void cross_fold_bias_kernel(const T* __restrict__ kv, const float* __restrict__ qb, float* __restrict__ c,
+                                                              int rows, int H, int heads) {
+    constexpr int VEC = Vec16<T>::N;
+    const int id = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (id >= rows * heads) return;
+    const int row = id / heads, h = id - row * heads, hd = H / heads;
+    float s = 0.f;
+    for (int ch = lane; ch < hd / VEC; ch += 64) {
+        const Vec16<T> k = ld16(kv + (long long)row * 2 * H + h * hd + ch * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s = fmaf(qb[h * hd + ch * VEC + e], to_f32<T>(k.v[e]), s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) c[id] = s;
+}
+
+template <typename T, int RG, int HEADS, bool MULTI> int launch_cross_fold_rg(const FoldArgs& a, hipStream_t s) {
+    const size_t lds = sizeof(float) * ((size_t)a.R * a.H + RG * HEADS * 64 + 8 * RG * (size_t)a.H + 2 * a.R);
+    MIC_ARG_CHECK(lds <= 150 * 1024, "mic_cross_attn_folded: %zu bytes of LDS needed", lds);
+    static bool granted = false;
+    if (!granted) {
+        MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_fold_kernel<T, RG, HEADS, MULTI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        granted = true;
+    }
+    MIC_LAUNCH((cross_fold_kernel<T, RG, HEADS, MULTI>), dim3(a.N / a.R), dim3(1024), lds, s, a);
+    return 0;
+}
+template <typename T, int HEADS> int launch_cross_fold(const FoldArgs& a, hipStream_t s) {
+    if (a.R <= 2) return launch_cross_fold_rg<T, 2, HEADS, false>(a, s);
+    if (a.R == 3) return launch_cross_fold_rg<T, 3, HEADS, false>(a, s);
+    if (a.R == 4) return launch_cross_fold_rg<T, 4, HEADS, false>(a, s);
+    if (a.R == 8 || a.R == 7) return launch_cross_fold_rg<T, 4, HEADS, true>(a, s);
+    return launch_cross_fold_rg<T, 3, HEADS, true>(a, s);
+}
+
 template <typename T, int RG> int launch_cross_wide_rg(const AttnArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * (RG * (size_t)a.heads * 64 + 8 * RG * (size_t)a.H);
     static bool granted = false;
@@ -830,6 +1082,46 @@ extern "C" int mic_cross_attn_step(const float* q, int ldq, const void* kv, int 
         if (lds <= 64 * 1024) return dtype == MIC_BF16 ? launch_cross_image<bf16_t>(a, s, lds) : launch_cross_image<float>(a, s, lds);
     }
     return dtype == MIC_BF16 ? launch_attn<bf16_t, false>(a, s) : launch_attn<float, false>(a, s);
+}
+
+extern "C" int mic_cross_attn_folded_supported(int dtype, int H, int heads, int S, int rows_per_image) {
+    if (dtype != MIC_F32 && dtype != MIC_BF16) return 0;
+    const int vec = 16 / (int)mic_dtype_size(dtype);
+    return H == 64 * vec && (heads == 1 || heads == 2) && S >= 1 && S <= 64 && rows_per_image >= 1 && rows_per_image <= MIC_MAX_BEAM;
+}
+
+extern "C" int mic_cross_fold_bias(const void* kv, const float* q_bias_scaled, float* c, int dtype, int rows, int H, int heads,
+                                   void* stream) {
+    MIC_ARG_CHECK(kv && q_bias_scaled && c, "mic_cross_fold_bias: null pointer");
+    MIC_TRY(check_attn_dims("mic_cross_fold_bias", dtype, rows, H, heads));
+    const int grid = (rows * heads + 3) / 4;
+    if (dtype == MIC_BF16)
+        MIC_LAUNCH(cross_fold_bias_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)kv, q_bias_scaled, c, rows, H, heads);
+    else
+        MIC_LAUNCH(cross_fold_bias_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)kv, q_bias_scaled, c, rows, H, heads);
+    return 0;
+}
+
+extern "C" int mic_cross_attn_folded(const mic_ln_ref* x, const void* kf, const void* vf, const float* c, const float* out_bias, int S,
+                                     int rows_per_image, float* y, float* stats_out, float* attn_out, int ld_attn, float attn_scale,
+                                     int accumulate, int dtype, int N, int H, int heads, void* stream) {
+    MIC_ARG_CHECK(x && x->raw && x->stats && x->gamma && x->beta && kf && vf && c && out_bias && y, "mic_cross_attn_folded: null pointer");
+    MIC_ARG_CHECK(mic_cross_attn_folded_supported(dtype, H, heads, S, rows_per_image),
+                  "mic_cross_attn_folded: unsupported shape (dtype %d, H=%d, heads=%d, S=%d, rows per image %d)", dtype, H, heads, S, rows_per_image);
+    MIC_ARG_CHECK(N > 0 && N % rows_per_image == 0, "mic_cross_attn_folded: N=%d is not a multiple of %d rows per image", N, rows_per_image);
+    MIC_ARG_CHECK(x->width == H && x->parts == (H + 127) / 128 && x->ld >= H && x->ld % 4 == 0, "mic_cross_attn_folded: LayerNorm view does not match H=%d", H);
+    MIC_ARG_CHECK(!attn_out || ld_attn >= S, "mic_cross_attn_folded: ld_attn=%d < S=%d", ld_attn, S);
+    MIC_ARG_CHECK(((uintptr_t)x->raw & 15) == 0 && ((uintptr_t)kf & 15) == 0 && ((uintptr_t)vf & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                      ((uintptr_t)x->gamma & 15) == 0 && ((uintptr_t)x->beta & 15) == 0,
+                  "mic_cross_attn_folded: 16-byte alignment");
+    FoldArgs a{};
+    a.raw = x->raw; a.stats = x->stats; a.gamma = x->gamma; a.beta = x->beta; a.ld = x->ld; a.parts = x->parts;
+    a.kf = kf; a.vf = vf; a.c = c; a.bo = out_bias; a.y = y; a.stats_out = stats_out;
+    a.attn_out = attn_out; a.ld_attn = ld_attn; a.attn_scale = attn_scale; a.accumulate = accumulate;
+    a.S = S; a.R = rows_per_image; a.N = N; a.H = H;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MIC_BF16) return heads == 1 ? launch_cross_fold<bf16_t, 1>(a, s) : launch_cross_fold<bf16_t, 2>(a, s);
+    return heads == 1 ? launch_cross_fold<float, 1>(a, s) : launch_cross_fold<float, 2>(a, s);
 }
 
 extern "C" int mic_lstm_cell(const float* gates, float* c, float* h, void* ht0, int ld0, void* ht1, int ld1, int dtype, int N,

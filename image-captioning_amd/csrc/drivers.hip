@@ -2,6 +2,8 @@
 // steps) on one stream so the host makes one call per phase instead of one per kernel.
 #include "mic_common.h"
 
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
 #include <string>
@@ -224,6 +226,18 @@ int res_ln(int dt, const void* wf, const void* in, int ld_in, int K, const void*
     return mic_layernorm(ws->y, g, be, ws->x, ws->xt, H, dt, N, H, s);
 }
 
+// the folded cross-attention sub-layer runs when the decoder carries the folded weights of layer l, the
+// workspace the folded K/V buffers, and the shape is one the kernel takes
+bool use_fold(const mic_tr_decoder* dec, const mic_tr_workspace* ws, int l) {
+    static const bool off = getenv("MIC_NO_CROSS_FOLD") != nullptr;
+    const mic_tr_layer& L = dec->layer[l];
+    if (off || dec->heads > MIC_FOLD_MAX_HEADS || !L.cross_qb_scaled || !ws->cross_kf[l] || !ws->cross_vf[l] || !ws->cross_c[l]) return false;
+    for (int h = 0; h < dec->heads; ++h)
+        if (!L.cross_kf_w[h] || !L.cross_vf_w[h]) return false;
+    const int epr = 64 / (int)mic_dtype_size(dec->dtype);
+    return (dec->H / dec->heads) % epr == 0 && mic_cross_attn_folded_supported(dec->dtype, dec->H, dec->heads, ws->S, ws->rows_per_image) != 0;
+}
+
 int check_tr(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
     MIC_ARG_CHECK(dec && ws, "transformer driver: null pointer");
     MIC_ARG_CHECK(dec->dtype == MIC_F32 || dec->dtype == MIC_BF16, "transformer driver: bad dtype");
@@ -248,6 +262,20 @@ extern "C" int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace
         MIC_ARG_CHECK(L.cross_kv_w && ws->cross_kv[l], "mic_tr_cross_kv: layer %d pointers missing", l);
         MIC_TRY(linear(dec->dtype, feats, H, rows, H, L.cross_kv_w, L.cross_kv_b, nullptr, 0, 0, ws->cross_kv[l], dec->dtype, 2 * H,
                        2 * H, 0, s));
+        if (use_fold(dec, ws, l)) {
+            // K'_h = k_h (W_q,h / sqrt d), V'_h = v_h W_o,h^T as per-head GEMMs over the rows of kv; c_h = b_q,h . k_h
+            const int heads = dec->heads, hd = H / heads;
+            const size_t sz = mic_dtype_size(dec->dtype);
+            for (int h = 0; h < heads; ++h) {
+                const char* kin = (const char*)ws->cross_kv[l] + (size_t)h * hd * sz;
+                const char* vin = kin + (size_t)H * sz;
+                MIC_TRY(linear(dec->dtype, kin, 2 * H, rows, hd, L.cross_kf_w[h], nullptr, nullptr, 0, 0,
+                               (char*)ws->cross_kf[l] + (size_t)h * H * sz, dec->dtype, heads * H, H, 0, s));
+                MIC_TRY(linear(dec->dtype, vin, 2 * H, rows, hd, L.cross_vf_w[h], nullptr, nullptr, 0, 0,
+                               (char*)ws->cross_vf[l] + (size_t)h * H * sz, dec->dtype, heads * H, H, 0, s));
+            }
+            MIC_TRY(mic_cross_fold_bias(ws->cross_kv[l], L.cross_qb_scaled, ws->cross_c[l], dec->dtype, rows, H, heads, s));
+        }
     }
     return 0;
 }
@@ -300,12 +328,6 @@ int tr_step_chained(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const
         }
         MIC_TRY(mic_self_attn_step(ws->qkv, ws->kcache[l], ws->vcache[l], anc, t, ws->t_cap, ws->o, H, dt, N, H, dec->heads, s));
         MIC_TRY(tail(ws->o, H, H, Y.self_out_wf, Y.self_out_b, Y.ln1_g, Y.ln1_b));
-        {
-            mic_skinny_desc d = base(Y.cross_q_wf, Y.cross_q_b, H, H);
-            set_x(d);
-            d.out = ws->qkv; d.out_dtype = MIC_F32; d.ldc = H;
-            MIC_TRY(mic_linear_skinny_ex(&d, s));
-        }
         float* ap = nullptr;
         int ld_attn = 0, accumulate = 0;
         float scale = 1.f;
@@ -314,9 +336,23 @@ int tr_step_chained(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const
         } else if (attn_mode == 2) {
             ap = ws->attn + ((int64_t)l * ws->t_cap + t) * N * S; ld_attn = S;
         }
-        MIC_TRY(mic_cross_attn_step(ws->qkv, H, ws->cross_kv[l], S, ws->rows_per_image, ws->o, H, ap, ld_attn, scale, accumulate, dt,
-                                    N, H, dec->heads, s));
-        MIC_TRY(tail(ws->o, H, H, Y.cross_out_wf, Y.cross_out_b, Y.ln2_g, Y.ln2_b));
+        if (use_fold(dec, ws, l)) {
+            // query projection, attention, output projection, residual and statistics in one launch
+            const mic_ln_ref xv = ln_view(ws->y, ws->stats[cs], pg, pb, H);
+            MIC_TRY(mic_cross_attn_folded(&xv, ws->cross_kf[l], ws->cross_vf[l], ws->cross_c[l], Y.cross_out_b, S, ws->rows_per_image,
+                                          ws->y, ws->stats[cs ^ 1], ap, ld_attn, scale, accumulate, dt, N, H, dec->heads, s));
+            cs ^= 1; pg = Y.ln2_g; pb = Y.ln2_b;
+        } else {
+            {
+                mic_skinny_desc d = base(Y.cross_q_wf, Y.cross_q_b, H, H);
+                set_x(d);
+                d.out = ws->qkv; d.out_dtype = MIC_F32; d.ldc = H;
+                MIC_TRY(mic_linear_skinny_ex(&d, s));
+            }
+            MIC_TRY(mic_cross_attn_step(ws->qkv, H, ws->cross_kv[l], S, ws->rows_per_image, ws->o, H, ap, ld_attn, scale, accumulate, dt,
+                                        N, H, dec->heads, s));
+            MIC_TRY(tail(ws->o, H, H, Y.cross_out_wf, Y.cross_out_b, Y.ln2_g, Y.ln2_b));
+        }
         {
             mic_skinny_desc d = base(Y.ff1_wf, Y.ff1_b, H, 2 * H);
             set_x(d);

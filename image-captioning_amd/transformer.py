@@ -108,6 +108,12 @@ class ImageCaptioner:
             "top_val": torch.empty(N, K, dtype=f32, device=dev), "top_idx": torch.empty(N, K, dtype=torch.int32, device=dev),
             "stats": torch.zeros(2, N, (H + 127) // 128, 2, dtype=f32, device=dev),
         }
+        heads = self.dec.heads
+        fold = bool(L.lib.mic_cross_attn_folded_supported(L.dtype_code(d), H, heads, S, rpi)) and bool(self.dec.layer[0].cross_qb_scaled)
+        if fold:  # folded cross keys / values (query and output projections applied once per image)
+            t["ckf"] = torch.empty(Ly, N // rpi, S, heads, H, dtype=d, device=dev)
+            t["cvf"] = torch.empty(Ly, N // rpi, S, heads, H, dtype=d, device=dev)
+            t["cc"] = torch.empty(Ly, N // rpi, S, heads, dtype=f32, device=dev)
         if attn_mode == 1:
             t["attn"] = torch.zeros(N, t_cap, S, dtype=f32, device=dev)
         elif attn_mode == 2:
@@ -118,6 +124,8 @@ class ImageCaptioner:
             setattr(ws, name, t[name].data_ptr())
         for l in range(Ly):
             ws.kcache[l], ws.vcache[l], ws.cross_kv[l] = t["kc"][l].data_ptr(), t["vc"][l].data_ptr(), t["ckv"][l].data_ptr()
+            if fold:
+                ws.cross_kf[l], ws.cross_vf[l], ws.cross_c[l] = t["ckf"][l].data_ptr(), t["cvf"][l].data_ptr(), t["cc"][l].data_ptr()
         ws.attn = t["attn"].data_ptr() if attn_mode else None
         ws.stats[0], ws.stats[1] = t["stats"][0].data_ptr(), t["stats"][1].data_ptr()
         if len(self._ws_cache) > 4 * self.decode_groups:

@@ -266,6 +266,18 @@ def build_tr_decoder(sd: SD, heads: int, dtype: torch.dtype, device) -> tuple:
             Y.self_in_wf = keep(frag_matrix(_pad_rows(ipw), dtype, device))
             Y.cross_q_wf = keep(frag_matrix(_pad_rows(sd[p + "cross_attention.mha.in_proj_weight"][:H]), dtype, device))
             Y.ff1_wf = keep(frag_matrix(_pad_rows(sd[p + "ff.seq.0.weight"]), dtype, device))
+        hd = H // heads
+        if heads <= L.FOLD_MAX_HEADS and hd % e == 0:
+            # fold the query projection into the cross keys and the output projection into the cross values
+            # (mic_cross_attn_folded): per head, K' = k_h (W_q,h / sqrt d) and V' = v_h W_o,h^T are plain GEMMs
+            wq = sd[p + "cross_attention.mha.in_proj_weight"][:H].double()
+            bq = sd[p + "cross_attention.mha.in_proj_bias"][:H].double()
+            wo = sd[p + "cross_attention.mha.out_proj.weight"].double()
+            sc = 1.0 / math.sqrt(hd)
+            for h in range(heads):
+                Y.cross_kf_w[h] = keep(matrix((wq[h * hd:(h + 1) * hd, :].T * sc).float().contiguous(), dtype, device))
+                Y.cross_vf_w[h] = keep(matrix(wo[:, h * hd:(h + 1) * hd].float().contiguous(), dtype, device))
+            Y.cross_qb_scaled = keep(vector((bq * sc).float(), device))
         for j, nm in enumerate(("self_attention", "cross_attention", "ff"), start=1):
             setattr(Y, f"ln{j}_g", keep(vector(sd[p + nm + ".layer_norm.weight"], device)))
             setattr(Y, f"ln{j}_b", keep(vector(sd[p + nm + ".layer_norm.bias"], device)))

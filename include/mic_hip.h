@@ -36,6 +36,7 @@ extern "C" {
 #define MIC_ACT_GELU 2      /* x/2 * (1 + erf(x / sqrt 2)); mic_conv2d only */
 
 #define MIC_MAX_BEAM 8      /* beam width accepted by the search kernels */
+#define MIC_FOLD_MAX_HEADS 2 /* head count up to which the cross-attention projections are folded into K/V */
 #define MIC_MAX_LAYERS 8    /* decoder depth accepted by the step drivers (sweeper/config.py:80 tops out at 6) */
 
 const char* mic_last_error(void);
@@ -219,6 +220,24 @@ int mic_cross_attn_step(const float* q, int ldq, const void* kv, int S, int rows
                         void* o, int ld_o, float* attn_out, int ld_attn, float attn_scale, int accumulate,
                         int dtype, int N, int H, int heads, void* stream);
 
+/* The whole cross-attention sub-layer of a post-LN decoder layer in ONE launch (models/transformer.py:
+ * 130-140: mha(query=x, key=value=image tokens) -> + x -> LayerNorm, the norm left to the consumer):
+ *     y = x + sum_h softmax_s( x . K'_h[s] + c_h[s] ) V'_h[s] + out_bias,     x = LN(x_ln->raw)
+ * with the query projection folded into per-image keys and the output projection into per-image values,
+ *     K'_h[s] = W_q,h^T k_h[s] / sqrt(d),  c_h[s] = b_q,h . k_h[s] / sqrt(d),  V'_h[s] = W_o[:, h-th slice] v_h[s],
+ * (kf, vf: [B][S][heads][H] of `dtype`; c: fp32 [B][S][heads]) which mic_tr_cross_kv prepares once per image
+ * when the decoder carries the folded weights.  Same mathematics as in-projection + attention + out-projection,
+ * re-associated; it removes two GEMM launches per layer per step.  Writes fp32 y [N][H] (may alias
+ * x_ln->raw) and, when stats_out != NULL, its row statistics per 128 columns (see mic_ln_ref).
+ * attn_out as in mic_cross_attn_step.  Supported (mic_cross_attn_folded_supported): H == 1024 bytes / sizeof
+ * element per row (512 bf16, 256 fp32), 1 or 2 heads, S <= 64, up to MIC_MAX_BEAM rows per image. */
+int mic_cross_attn_folded_supported(int dtype, int H, int heads, int S, int rows_per_image);
+int mic_cross_attn_folded(const mic_ln_ref* x_ln, const void* kf, const void* vf, const float* c, const float* out_bias, int S,
+                          int rows_per_image, float* y, float* stats_out, float* attn_out, int ld_attn, float attn_scale,
+                          int accumulate, int dtype, int N, int H, int heads, void* stream);
+/* c[row][h] = q_bias_scaled[h-th slice] . k[row][h-th slice] for `rows` key rows of kv [rows][2H] (k then v). */
+int mic_cross_fold_bias(const void* kv, const float* q_bias_scaled, float* c, int dtype, int rows, int H, int heads, void* stream);
+
 /* LSTM cell pointwise part, gate order i,f,g,o (nn.LSTM, models/basic.py:48,
  * models/intermediate.py:63): c' = s(f)*c + s(i)*tanh(g); h' = s(o)*tanh(c').  gates fp32
  * [N][4*Hd]; c, h fp32 [N][Hd] updated in place; h' is also written in `dtype` to ht0 (row stride
@@ -365,6 +384,13 @@ typedef struct mic_tr_layer {
     /* optional: self_in_w / cross_q_w / ff1_w (rows padded to 128) in fragment order for
      * mic_linear_skinny; used when set and the row count is at most 2048. */
     const void *self_in_wf, *cross_q_wf, *ff1_wf;
+    /* optional, for at most MIC_FOLD_MAX_HEADS heads: per-head matrices that fold the query projection into the
+     * cross keys (cross_kf_w[h] = (W_q rows of head h)^T / sqrt(d), [H padded][d]) and the output projection into
+     * the cross values (cross_vf_w[h] = W_o columns of head h, [H padded][d]), and the query bias / sqrt(d).
+     * With them and the workspace buffers below the step driver runs mic_cross_attn_folded. */
+    const void* cross_kf_w[2];
+    const void* cross_vf_w[2];
+    const float* cross_qb_scaled;
 } mic_tr_layer;
 
 typedef struct mic_tr_decoder {
@@ -396,6 +422,9 @@ typedef struct mic_tr_workspace {
     int32_t* top_idx;
     float* stats[2]; /* optional, each [N][ceil(H/128)][2]: row statistics for the LayerNorm-free step
                         (used when set, N <= 2048 and every fragment-ordered weight is present) */
+    void* cross_kf[MIC_MAX_LAYERS];   /* optional, each [N/rows_per_image][S][heads][H] dtype: folded keys */
+    void* cross_vf[MIC_MAX_LAYERS];   /*           same shape: folded values */
+    float* cross_c[MIC_MAX_LAYERS];   /*           [N/rows_per_image][S][heads] fp32 */
 } mic_tr_workspace;
 
 /* Cross-attention keys/values of every layer from image tokens feats [B][S][H] (dtype):

@@ -203,3 +203,33 @@ def test_lstm_sampling_matches_oracle_on_shared_uniforms(amd, golden_lstm):
     u = torch.rand(12, 4, generator=torch.Generator().manual_seed(5))
     ref = O.lstm_generate(sd, "intermediate", feats, 12, 1.3, 1, O.inverse_cdf_sampler(u.double()))
     assert model.generate_from_features(feats, None, 12, 1.3, 1, uniforms=u) == ref
+
+
+@pytest.mark.parametrize("heads", [1, 2])
+def test_transformer_fp32_hidden_256_matches_oracle(amd, heads):
+    """A decoder at the hidden size whose fp32 rows are 1 KiB: the shapes that take the wave-per-position attention
+    kernels and, with one or two heads, the cross-attention sub-layer with folded projections.  Not covered by the
+    reference-generated fixtures (H=64), so the check is against the oracle running the same random weights."""
+    from oracle import captioner_oracle as O
+    V, H, Ly, PT, B, S = 400, 256, 2, 24, 5, 49
+    sd = amd.weights.random_transformer_state(V, H, Ly, PT, seed=11 + heads)
+    g = torch.Generator().manual_seed(5)
+    for k in list(sd):  # biases and LayerNorm parameters away from their trivial initial values
+        if k.endswith("in_proj_bias") or k.endswith("out_proj.bias"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("layer_norm.weight"):
+            sd[k] = 1 + 0.2 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("layer_norm.bias"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+    vocab = IdVocab(V)
+    model = amd.transformer.ImageCaptioner.from_state_dict(sd, vocab, heads, torch.float32, "cuda:0")
+    feats_bchw = torch.randn(B, H, 7, 7, generator=g).relu()
+    feats = O.tokens_major(feats_bchw)
+    for K in (1, 3, 5):
+        ref_tok, ref_lp, ref_attn = O.transformer_generate(sd, heads, feats_bchw, 14, None, K)
+        caps, lp, attn = model.generate_from_features(feats, vocab, 14, None, K, True)
+        assert caps == [vocab.encode_as_words(t) for t in ref_tok], f"beam {K}"
+        np.testing.assert_allclose(lp.cpu().numpy(), ref_lp.numpy(), **F32_TOL)
+        if K > 1:
+            for i, a in enumerate(attn):
+                np.testing.assert_allclose(np.array(a, dtype=np.float32), np.array(ref_attn[i], dtype=np.float32)[: len(a)], **F32_TOL)

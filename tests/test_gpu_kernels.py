@@ -316,6 +316,72 @@ def test_cross_attention_one_workgroup_per_image(L, dtype, H, heads, rpi, S):
     assert torch.equal(o, o2)
 
 
+@pytest.mark.parametrize("dtype,H,heads", [(torch.bfloat16, 512, 2), (torch.bfloat16, 512, 1), (torch.float32, 256, 2)])
+@pytest.mark.parametrize("rpi,S", [(1, 49), (3, 49), (4, 64), (5, 33), (8, 49)])
+def test_cross_attention_folded_sublayer(L, W, dtype, H, heads, rpi, S):
+    """y = LN(r) + MHA(LN(r), kv, kv) with the q / out projections folded into per-image K', V' (built here the way
+    mic_tr_cross_kv does: per-head GEMMs + the bias kernel), against the unfolded mathematics on the CPU."""
+    g = torch.Generator().manual_seed(H + heads + rpi + S)
+    B, hd, code = 4, H // heads, L.dtype_code(dtype)
+    N, parts = B * rpi, (H + 127) // 128
+
+    def q_(t):
+        return t.to(dtype).float() if dtype == torch.bfloat16 else t
+
+    r = torch.randn(N, H, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    wq, bq = torch.randn(H, H, generator=g) / math.sqrt(H), 0.1 * torch.randn(H, generator=g)
+    wo, bo = torch.randn(H, H, generator=g) / math.sqrt(H), 0.1 * torch.randn(H, generator=g)
+    kv = q_(torch.randn(B, S, 2 * H, generator=g))
+    sc = 1.0 / math.sqrt(hd)
+    # device-side preparation through the library: per-head folded weights -> K', V' (GEMM), c (bias kernel)
+    kvd = kv.to(DEV, dtype)
+    kf = torch.empty(B, S, heads, H, dtype=dtype, device=DEV)
+    vf = torch.empty(B, S, heads, H, dtype=dtype, device=DEV)
+    cc = torch.empty(B, S, heads, device=DEV)
+    keep = []
+    sz = kvd.element_size()
+    for h in range(heads):
+        for dst, wmat, off in ((kf, (wq[h * hd:(h + 1) * hd, :].T * sc).contiguous(), h * hd), (vf, wo[:, h * hd:(h + 1) * hd].contiguous(), H + h * hd)):
+            wm = W.matrix(wmat, dtype, DEV)
+            keep.append(wm)
+            d = L.ConvDesc()
+            d.in_, d.w, d.out = kvd.data_ptr() + off * sz, wm.data_ptr(), dst.data_ptr() + h * H * sz
+            d.dtype = d.out_dtype = d.res_dtype = code
+            d.M, d.N, d.K = B * S, H, hd
+            d.OH = d.OW = d.IH = d.IW = 1
+            d.in_img_stride, d.in_pix_stride, d.kw_taps, d.run, d.stride, d.ldc = 2 * H, 4, 1, hd, 1, heads * H
+            L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()))
+    qbs = (bq * sc).to(DEV)
+    L.check(L.lib.mic_cross_fold_bias(kvd.data_ptr(), qbs.data_ptr(), cc.data_ptr(), code, B * S, H, heads, L.stream_ptr()))
+    # statistics of r per 128 columns, as a producer launch would have written them
+    rp = r.view(N, parts, -1)
+    stats = torch.stack([rp.mean(-1), ((rp - rp.mean(-1, keepdim=True)) ** 2).sum(-1)], dim=-1).contiguous()
+    rd, sd_, gd, bd, bod = r.to(DEV), stats.to(DEV), gamma.to(DEV), beta.to(DEV), bo.to(DEV)
+    y = torch.empty(N, H, device=DEV)
+    so = torch.empty(N, parts, 2, device=DEV)
+    attn = torch.zeros(N, S, device=DEV)
+    xv = L.LnRef(rd.data_ptr(), sd_.data_ptr(), gd.data_ptr(), bd.data_ptr(), H, parts, H)
+    L.check(L.lib.mic_cross_attn_folded(C.byref(xv), kf.data_ptr(), vf.data_ptr(), cc.data_ptr(), bod.data_ptr(), S, rpi, y.data_ptr(),
+                                        so.data_ptr(), attn.data_ptr(), S, 1.0, 0, code, N, H, heads, L.stream_ptr()))
+    x = F.layer_norm(r, (H,), gamma, beta, 1e-5)
+    qh = (F.linear(x, wq, bq) * sc).view(B, rpi, heads, hd)
+    k_, v_ = kv[:, :, :H].view(B, S, heads, hd), kv[:, :, H:].view(B, S, heads, hd)
+    w = torch.softmax(torch.einsum("brhd,bshd->brhs", qh, k_), dim=-1)
+    ref = x + F.linear(torch.einsum("brhs,bshd->brhd", w, v_).reshape(N, H), wo, bo)
+    tol = dict(rtol=1e-3, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), **tol)
+    np.testing.assert_allclose(attn.cpu().numpy(), w.mean(dim=2).reshape(N, S).numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=1e-4)
+    yp = y.cpu().view(N, parts, -1)
+    np.testing.assert_allclose(so.cpu()[..., 0].numpy(), yp.mean(-1).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(so.cpu()[..., 1].numpy(), ((yp - yp.mean(-1, keepdim=True)) ** 2).sum(-1).numpy(), rtol=1e-4, atol=1e-4)
+    # in place (y aliasing the raw stream), as the step driver calls it
+    L.check(L.lib.mic_cross_attn_folded(C.byref(xv), kf.data_ptr(), vf.data_ptr(), cc.data_ptr(), bod.data_ptr(), S, rpi, rd.data_ptr(),
+                                        so.data_ptr(), None, 0, 1.0, 0, code, N, H, heads, L.stream_ptr()))
+    assert torch.equal(rd, y)
+    assert L.lib.mic_cross_attn_folded_supported(code, H, 4, S, rpi) == 0 and L.lib.mic_cross_attn_folded_supported(code, H + 64, heads, S, rpi) == 0
+
+
 @pytest.mark.parametrize("V", [200, 3500, 4096, 4097, 6501])
 @pytest.mark.parametrize("K", [1, 3, 5, 8])
 def test_logsoftmax_topk(L, V, K):
