@@ -258,9 +258,11 @@ def build_tr_decoder(sd: SD, heads: int, dtype: torch.dtype, device) -> tuple:
         Y.ff2_w, Y.ff2_b = keep(matrix(sd[p + "ff.seq.2.weight"], dtype, device)), keep(vector(sd[p + "ff.seq.2.bias"], device))
         e = k_multiple(dtype)
         if L.lib.mic_linear_res_ln_supported(H) and H % e == 0:
-            Y.self_out_wf = keep(frag_matrix(sd[p + "self_attention.mha.out_proj.weight"], dtype, device))
-            Y.cross_out_wf = keep(frag_matrix(sd[p + "cross_attention.mha.out_proj.weight"], dtype, device))
-            Y.ff2_wf = keep(frag_matrix(sd[p + "ff.seq.2.weight"], dtype, device))
+            # rows padded to 128 like every fragment-ordered matrix: the skinny GEMM's workgroups span 128
+            # columns and fetch the (zero) tiles past H; the fused GEMM+LayerNorm kernel reads the first H rows only
+            Y.self_out_wf = keep(frag_matrix(_pad_rows(sd[p + "self_attention.mha.out_proj.weight"]), dtype, device))
+            Y.cross_out_wf = keep(frag_matrix(_pad_rows(sd[p + "cross_attention.mha.out_proj.weight"]), dtype, device))
+            Y.ff2_wf = keep(frag_matrix(_pad_rows(sd[p + "ff.seq.2.weight"]), dtype, device))
         if H % e == 0:  # fragment-ordered copies (rows zero-padded to 128) for the skinny GEMM
             ipw = sd[p + "self_attention.mha.in_proj_weight"]
             Y.self_in_wf = keep(frag_matrix(_pad_rows(ipw), dtype, device))

@@ -377,9 +377,10 @@ typedef struct mic_tr_layer {
     const void *self_in_w, *self_out_w, *cross_q_w, *cross_kv_w, *cross_out_w, *ff1_w, *ff2_w; /* dtype, padded */
     const float *self_in_b, *self_out_b, *cross_q_b, *cross_kv_b, *cross_out_b, *ff1_b, *ff2_b;
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
-    /* optional: self_out_w / cross_out_w / ff2_w in fragment order (mic_pack_weight_frag).  When all
-     * three are set and the hidden size has a fused variant, the step driver runs
-     * mic_linear_res_ln instead of GEMM + LayerNorm for the three sub-layer tails. */
+    /* optional: self_out_w / cross_out_w / ff2_w, rows zero-padded to a multiple of 128, in fragment order
+     * (mic_pack_weight_frag).  The step driver feeds them to mic_linear_skinny_ex (whose workgroups fetch
+     * whole 128-column groups, hence the padding) or, above 2048 rows and when the hidden size has a
+     * fused variant, to mic_linear_res_ln (which reads the first H rows only). */
     const void *self_out_wf, *cross_out_wf, *ff2_wf;
     /* optional: self_in_w / cross_q_w / ff1_w (rows padded to 128) in fragment order for
      * mic_linear_skinny; used when set and the row count is at most 2048. */
