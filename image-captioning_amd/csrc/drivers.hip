@@ -376,7 +376,8 @@ extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws
     MIC_ARG_CHECK(attn_mode == 0 || ws->attn, "mic_tr_step: attention requested without a buffer");
     hipStream_t s = (hipStream_t)stream;
     const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
-    bool chain = N <= 2048 && ws->stats[0] && ws->stats[1] && dec->out_wf && H % 4 == 0 && H <= 1024;
+    static const int chain_max = [] { const char* e = getenv("MIC_CHAIN_MAX_ROWS"); return e ? atoi(e) : 2048; }();
+    bool chain = N <= chain_max && ws->stats[0] && ws->stats[1] && dec->out_wf && H % 4 == 0 && H <= 1024;
     for (int l = 0; l < L && chain; ++l) {
         const mic_tr_layer& Y = dec->layer[l];
         chain = Y.self_in_wf && Y.self_out_wf && Y.cross_q_wf && Y.cross_out_wf && Y.ff1_wf && Y.ff2_wf;
