@@ -17,7 +17,7 @@ import torch
 from . import _lib as L
 from . import weights as W
 from .encoders import ResNet50Encoder, SwinV2Encoder
-from .vocabulary import EOS, PAD, SOS
+from .vocabulary import EOS, PAD, SOS, UNK
 
 
 class ImageCaptioner:
@@ -276,6 +276,57 @@ class ImageCaptioner:
         if self.encoder is None:
             raise RuntimeError("this captioner was built without an encoder; pass features to generate_from_features")
         return self.encoder(images)
+
+    # ---- teacher-forced evaluation (no autograd: inference-side loss only) -----------------------
+    def forward_from_features(self, feats: torch.Tensor, captions: torch.Tensor, want_lse: bool = False):
+        """models/transformer.py:338-363 downstream of the encoder: next-token logits (B, T, V) fp32 for every
+        position of ``captions`` (B, T), computed by stepping the cached decoder over the given tokens (position p
+        sees tokens 0..p, exactly what the causal mask lets the reference see).  With ``want_lse`` also returns
+        log-sum-exp of every row (B, T), from the library's log-softmax kernel."""
+        feats = self._check_feats(feats)
+        B, S, _ = feats.shape
+        if captions.dim() != 2 or captions.shape[0] != B:
+            raise ValueError(f"expected captions of shape ({B}, T), got {tuple(captions.shape)}")
+        T = captions.shape[1]
+        if T < 1 or T > self.max_len:
+            raise ValueError(f"caption length {T} outside [1, {self.max_len}] (position table size)")
+        dev, V = self.device, self.dec.vocab
+        cap = captions.to(dev, torch.int32).contiguous()
+        ws, t = self._workspace(B, T, S, 1, 1, 0)
+        out = torch.empty(B, T, V, dtype=torch.float32, device=dev)
+        lse = torch.empty(T, B, dtype=torch.float32, device=dev) if want_lse else None
+        stream = L.stream_ptr()
+        L.check(L.lib.mic_tr_cross_kv(C.byref(self.dec), C.byref(ws), feats.data_ptr(), stream), "mic_tr_cross_kv")
+        for p in range(T):
+            L.check(L.lib.mic_tr_step(C.byref(self.dec), C.byref(ws), cap.data_ptr(), T, None, p, 0, stream), "mic_tr_step")
+            if want_lse:
+                L.check(L.lib.mic_logsoftmax_topk(t["logits"].data_ptr(), V, B, V, 1, 1.0, 0, t["top_val"].data_ptr(),
+                                                  t["top_idx"].data_ptr(), lse[p].data_ptr(), stream), "mic_logsoftmax_topk")
+            out[:, p].copy_(t["logits"])
+        return (out, lse.t().contiguous()) if want_lse else out
+
+    def forward(self, images: torch.Tensor, captions: torch.Tensor) -> torch.Tensor:
+        """models/transformer.py:338-363 (eval mode; the training path with autograd is out of scope)."""
+        if self.device is None:
+            raise RuntimeError("call .to(device) first")
+        return self.forward_from_features(self.encode(images), captions)
+
+    __call__ = forward
+
+    def evaluation_loss(self, images: torch.Tensor, captions: torch.Tensor, vocab=None, feats: Optional[torch.Tensor] = None):
+        """train.forward_pass (train.py:318-354) without gradients: summed cross-entropy of captions[:, 1:] given
+        captions[:, :-1], over targets other than PAD / SOS / UNK, and the number of such targets."""
+        vocab = vocab if vocab is not None else self.vocab
+        feats = self.encode(images) if feats is None else feats
+        logits, lse = self.forward_from_features(feats, captions[:, :-1], want_lse=True)
+        targets = captions[:, 1:].to(self.device, torch.int64)
+        picked = logits.gather(2, targets.clamp(0, self.dec.vocab - 1).unsqueeze(-1)).squeeze(-1)
+        mask = torch.ones_like(targets, dtype=torch.bool)
+        for tok in (PAD, SOS, UNK):
+            mask &= targets != vocab.str_to_idx(tok)
+        n = int(mask.sum().item())
+        loss = ((lse - picked) * mask).sum() if n > 0 else torch.zeros((), device=self.device)
+        return loss, n
 
     def generate_from_features(self, feats, vocab, max_len: int, temp, beam_size: int, return_attn: bool = False,
                                uniforms=None) -> tuple:

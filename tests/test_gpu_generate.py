@@ -233,3 +233,28 @@ def test_transformer_fp32_hidden_256_matches_oracle(amd, heads):
         if K > 1:
             for i, a in enumerate(attn):
                 np.testing.assert_allclose(np.array(a, dtype=np.float32), np.array(ref_attn[i], dtype=np.float32)[: len(a)], **F32_TOL)
+
+
+@pytest.mark.parametrize("S", [49, 64])
+def test_transformer_forward_and_evaluation_loss(amd, golden_transformer, S):
+    """The public teacher-forced forward (models/transformer.py:338-363) against the reference's logits, and the
+    evaluation loss of train.forward_pass (train.py:318-354) against cross-entropy of those reference logits."""
+    import torch.nn.functional as F
+    from oracle import captioner_oracle as O
+    g = golden_transformer
+    model = _tr_model(amd, g, "plain")
+    feats = O.tokens_major(torch.from_numpy(g[f"tf{S}/features"]))
+    cap = torch.from_numpy(g[f"tf{S}/captions"]).long()
+    ref = torch.from_numpy(g[f"tf{S}/logits"])
+    got = model.forward_from_features(feats, cap).cpu()
+    live = ref.abs() < 1e8
+    np.testing.assert_allclose(got[live].numpy(), ref[live].numpy(), rtol=1e-3, atol=1e-3)
+    # loss: feed captions[:, :-1], score captions[:, 1:], skipping PAD / SOS / UNK targets
+    loss, n = model.evaluation_loss(None, cap, model.vocab, feats=feats)
+    tgt = cap[:, 1:]
+    mask = (tgt != 0) & (tgt != 1) & (tgt != 3)
+    ce = F.cross_entropy(ref[:, :-1].reshape(-1, ref.shape[-1]), tgt.reshape(-1), reduction="none").view(tgt.shape)
+    assert n == int(mask.sum())
+    np.testing.assert_allclose(float(loss), float((ce * mask).sum()), rtol=1e-3)
+    with pytest.raises(ValueError):
+        model.forward_from_features(feats, cap[:1])
