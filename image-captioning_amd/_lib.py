@@ -122,6 +122,7 @@ SIGNATURES = {
     "mic_profile_begin": (C.c_int, [C.c_int]),
     "mic_profile_end": (C.c_int, [P(i32), P(C.c_double), P(C.c_double)]),
     "mic_pack_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_resize_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(f32), P(f32), C.c_int, vp]),
     "mic_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_global_avgpool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_embed_pos": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

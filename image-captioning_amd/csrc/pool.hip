@@ -92,7 +92,85 @@ inline int grid_for(long long total, int block) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+// Antialiased bilinear resize (triangle filter whose support grows with the downscale factor, the
+// algorithm behind interpolate(mode="bilinear", antialias=True)) of uint8 HWC images, optional rounding
+// back to uint8 levels, /255, per-channel (x - mean) / std, planar fp32 out.  One thread per output pixel;
+// the taps of both axes are bounded by the clamped windows [ymin, ymin+ysize) x [xmin, xmin+xsize).
+struct ResizeArgs {
+    const unsigned char* src;  // [B][H][W][3]
+    float* dst;                // [B][3][OH][OW]
+    int B, H, W, OH, OW, round_u8;
+    float mean[3], inv_std[3];
+};
+
+__device__ __forceinline__ void aa_window(int o, float scale, int in_size, int& lo, int& size, float& center, float& invscale) {
+    const float support = scale >= 1.0f ? scale : 1.0f;
+    center = scale * ((float)o + 0.5f);
+    invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    lo = max((int)(center - support + 0.5f), 0);
+    size = min((int)(center + support + 0.5f), in_size) - lo;
+}
+__device__ __forceinline__ float aa_weight(int j, int lo, float center, float invscale) {
+    const float x = fabsf(((float)(j + lo) - center + 0.5f) * invscale);
+    return x < 1.0f ? 1.0f - x : 0.0f;
+}
+
+__global__ void resize_normalize_kernel(const ResizeArgs a) {
+    const long long total = (long long)a.B * a.OH * a.OW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % a.OW), oy = (int)((idx / a.OW) % a.OH), b = (int)(idx / ((long long)a.OW * a.OH));
+    const float sy = (float)a.H / (float)a.OH, sx = (float)a.W / (float)a.OW;
+    int ylo, ysz, xlo, xsz;
+    float yc, yi, xc, xi;
+    aa_window(oy, sy, a.H, ylo, ysz, yc, yi);
+    aa_window(ox, sx, a.W, xlo, xsz, xc, xi);
+    float wxs = 0.f, wys = 0.f;
+    for (int i = 0; i < xsz; ++i) wxs += aa_weight(i, xlo, xc, xi);
+    for (int j = 0; j < ysz; ++j) wys += aa_weight(j, ylo, yc, yi);
+    float acc[3] = {0.f, 0.f, 0.f};
+    const unsigned char* img = a.src + (long long)b * a.H * a.W * 3;
+    for (int j = 0; j < ysz; ++j) {
+        const float wy = aa_weight(j, ylo, yc, yi);
+        const unsigned char* row = img + ((long long)(ylo + j) * a.W + xlo) * 3;
+        float r[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < xsz; ++i) {
+            const float wx = aa_weight(i, xlo, xc, xi);
+            r[0] = fmaf(wx, (float)row[3 * i], r[0]);
+            r[1] = fmaf(wx, (float)row[3 * i + 1], r[1]);
+            r[2] = fmaf(wx, (float)row[3 * i + 2], r[2]);
+        }
+        acc[0] = fmaf(wy, r[0], acc[0]);
+        acc[1] = fmaf(wy, r[1], acc[1]);
+        acc[2] = fmaf(wy, r[2], acc[2]);
+    }
+    const float norm = 1.0f / (wxs * wys);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = acc[c] * norm;
+        if (a.round_u8) v = fminf(fmaxf(floorf(v + 0.5f), 0.f), 255.f);
+        a.dst[(((long long)b * 3 + c) * a.OH + oy) * a.OW + ox] = (v * (1.0f / 255.0f) - a.mean[c]) * a.inv_std[c];
+    }
+    }
+}
+
 }  // namespace
+
+extern "C" int mic_resize_normalize(const uint8_t* src, float* dst, int B, int H, int W, int OH, int OW, const float mean[3],
+                                    const float std[3], int round_u8, void* stream) {
+    MIC_ARG_CHECK(src && dst && mean && std, "mic_resize_normalize: null pointer");
+    MIC_ARG_CHECK(B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "mic_resize_normalize: bad sizes B=%d %dx%d -> %dx%d", B, H, W, OH, OW);
+    MIC_ARG_CHECK((long long)H <= 64ll * OH && (long long)W <= 64ll * OW, "mic_resize_normalize: downscale beyond 64x is not supported");
+    ResizeArgs a;
+    a.src = src; a.dst = dst; a.B = B; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.round_u8 = round_u8;
+    for (int c = 0; c < 3; ++c) {
+        MIC_ARG_CHECK(std[c] > 0.f, "mic_resize_normalize: std[%d] must be positive", c);
+        a.mean[c] = mean[c];
+        a.inv_std[c] = 1.0f / std[c];
+    }
+    const long long total = (long long)B * OH * OW;
+    MIC_LAUNCH(resize_normalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return 0;
+}
 
 extern "C" int mic_pack_image(const float* nchw, void* out, int dtype, int B, int H, int W, int pad_t, int pad_b, int pad_l,
                               int pad_r, void* stream) {

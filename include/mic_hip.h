@@ -101,6 +101,15 @@ int mic_profile_end(int32_t count[4], double ms[4], double flops[4]);
 int mic_pack_image(const float* nchw, void* out, int dtype, int B, int H, int W,
                    int pad_t, int pad_b, int pad_l, int pad_r, void* stream);
 
+/* Input transform of the reference on the device (runner/config.py:7-12: v2.ToImage, v2.Resize((256,256)),
+ * v2.ToDtype(float32, scale=True), v2.Normalize): src uint8 [B][H][W][3] (decoded RGB, interleaved) ->
+ * dst fp32 [B][3][OH][OW] = (resize(src) / 255 - mean) / std with the antialiased bilinear (triangle)
+ * filter of interpolate(mode="bilinear", antialias=True), which is what v2.Resize applies to tensors.
+ * round_u8 != 0 rounds the resized value to an integer level first, as the reference's uint8 intermediate
+ * does.  mean / std are HOST arrays of 3.  Downscale factors up to 64 per axis. */
+int mic_resize_normalize(const uint8_t* src, float* dst, int B, int H, int W, int OH, int OW, const float mean[3],
+                         const float std[3], int round_u8, void* stream);
+
 /* 3x3 stride-2 pad-1 max pooling, NHWC (torchvision resnet50 child 3, nn.MaxPool2d(3,2,1)). */
 int mic_maxpool3x3s2(const void* in, void* out, int dtype, int B, int H, int W, int C, void* stream);
 
