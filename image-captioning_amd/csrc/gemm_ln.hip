@@ -187,7 +187,7 @@ struct SkinnyArgs {
     LnRef rl;
     void* out;
     float* stats_out;
-    int ld_x, ld_res, ldc, M, N, K, relu, out_dtype, col_blocks;
+    int ld_x, ld_res, ldc, M, N, K, relu, out_dtype, col_blocks, xcd_rows;
 };
 
 // mean and 1/sqrt(var + eps) of one row from its per-part (mean, M2) pairs
@@ -216,7 +216,21 @@ __global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : 1) void skinn
     __shared__ float rs_x[ROWS][2], rs_r[ROWS][2], red[2][NWV][ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int cb = blockIdx.x % a.col_blocks, rb = blockIdx.x / a.col_blocks;
+    // Workgroups b and b+8 run on the same XCD (and share its L2).  All column blocks of a row block go to
+    // one XCD, and row block rb always to XCD rb % 8, so that the activation rows are fetched into one L2
+    // and the next launch of the chain finds the rows its predecessor wrote on the XCD that wrote them.
+    int cb, rb;
+    {
+        const int rbs = gridDim.x / a.col_blocks;
+        if ((rbs & 7) == 0 && a.xcd_rows) {
+            const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+            cb = j % a.col_blocks;
+            rb = x + 8 * (j / a.col_blocks);
+        } else {
+            cb = blockIdx.x % a.col_blocks;
+            rb = blockIdx.x / a.col_blocks;
+        }
+    }
     const int m0 = rb * ROWS, nb = cb * 128 + wave * TPW * 16;
     const int nk = a.K / EPR;
     const int xrow = a.K * (int)sizeof(T) + 16;
@@ -421,6 +435,8 @@ template <typename T, int MT, int NWV = 4> int launch_skinny(SkinnyArgs& a, hipS
         }
     }
     a.col_blocks = (a.N + 127) / 128;
+    static const int xcd_rows = [] { const char* e = getenv("MIC_SKINNY_XCD_ROWS"); return e ? atoi(e) : 1; }();
+    a.xcd_rows = xcd_rows;
     const int grid = a.col_blocks * ((a.M + MT * 16 - 1) / (MT * 16));
     MIC_LAUNCH((skinny_gemm_kernel<T, MT, NWV>), dim3(grid), dim3(64 * NWV), lds, s, a);
     return 0;
