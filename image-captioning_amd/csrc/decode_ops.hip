@@ -286,7 +286,15 @@ __global__ __launch_bounds__(256) void self_attn_wide_kernel(const AttnArgs a) {
     const int lph = 64 / heads;
     float* sc = smem;                 // [heads][SP]
     float* part = smem + heads * SP;  // [4][H]
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane / lph;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane / lph;
+    // Workgroup b runs on XCD b % 8; the projection that wrote rows 16*rb .. 16*rb+15 ran on XCD rb % 8 and the
+    // one that reads this kernel's output will too, so row n is handled on XCD (n / 16) % 8 when the row count
+    // divides into 8 XCDs x 16 rows (a bijection of [0, N) then).
+    int n = blockIdx.x;
+    if ((gridDim.x & 127) == 0) {
+        const int x = n & 7, j = n >> 3;
+        n = (((j >> 4) << 3) + x) * 16 + (j & 15);
+    }
     const float scale = sqrtf(1.0f / (float)(H / heads));
     const float* qrow = a.q + (long long)n * a.ldq + lane * VEC;
     Vec16<T> knew, vnew;  // position t: the fresh projection rounded through T, as the cache will hold it

@@ -490,3 +490,70 @@ extern "C" int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspa
     return linear(dt, ws->hnt, dec->out_k, N, dec->out_k, dec->out_w, dec->out_b, nullptr, 0, 0, ws->logits, MIC_F32, dec->vocab,
                   dec->vocab, 0, s);
 }
+
+namespace {
+int check_lstm_pair(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, int n_ws, int t0, int t1, int t_cap, const char* who) {
+    MIC_ARG_CHECK(dec && ws, "%s: null pointer", who);
+    MIC_ARG_CHECK(t0 >= 0 && t1 >= t0 && t1 + 1 <= t_cap, "%s: steps [%d,%d) do not fit t_cap=%d", who, t0, t1, t_cap);
+    for (int i = 0; i < n_ws; ++i) MIC_ARG_CHECK(ws[i].N == ws[0].N && ws[i].logits, "%s: workspaces differ in rows or lack logits", who);
+    return 0;
+}
+}  // namespace
+
+// Steps [t0, t1) of LSTM beam search.  Step t runs on workspace t & 1; the survivors' recurrent state
+// (h, c and the [x | h] GEMM input of every layer) is gathered by parent row into workspace (t + 1) & 1.
+extern "C" int mic_lstm_beam_steps(const mic_lstm_decoder* dec, const mic_lstm_workspace ws[2], const mic_beam_state st[2],
+                                   int32_t* parent, int32_t* live_images, const double* sqrt_tab, float* top_val, int32_t* top_idx,
+                                   int B, int K, int t0, int t1, int t_cap, int eos_id, int use_graph, void* stream) {
+    MIC_TRY(check_lstm_pair(dec, ws, 2, t0, t1, t_cap, "mic_lstm_beam_steps"));
+    MIC_ARG_CHECK(st && parent && live_images && sqrt_tab && top_val && top_idx, "mic_lstm_beam_steps: null pointer");
+    MIC_ARG_CHECK(B > 0 && K > 0 && B * K == ws[0].N, "mic_lstm_beam_steps: workspace rows %d != B*K = %d*%d", ws[0].N, B, K);
+    MIC_ARG_CHECK(dec->layers >= 1 && dec->layers <= MIC_MAX_LAYERS, "mic_lstm_beam_steps: bad layer count %d", dec->layers);
+    const int N = B * K;
+    const int sz = (int)mic_dtype_size(dec->dtype);
+    auto body = [&](void* stream) -> int {
+        for (int t = t0; t < t1; ++t) {
+            const mic_lstm_workspace* wc = &ws[t & 1];
+            const mic_lstm_workspace* wn = &ws[(t + 1) & 1];
+            const mic_beam_state* cur = &st[t & 1];
+            const mic_beam_state* nxt = &st[(t + 1) & 1];
+            MIC_TRY(mic_lstm_step(dec, wc, cur->seq, t_cap, t, nullptr, 0, stream));
+            MIC_TRY(mic_logsoftmax_topk(wc->logits, dec->vocab, N, dec->vocab, K, 1.0f, 0, top_val, top_idx, nullptr, stream));
+            MIC_TRY(mic_beam_select(cur, nxt, top_val, top_idx, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t, t_cap,
+                                    eos_id, 1, stream));
+            for (int l = 0; l < dec->layers; ++l) {
+                MIC_TRY(mic_gather_rows(wc->h[l], wn->h[l], parent, N, dec->Hd * 4, stream));
+                MIC_TRY(mic_gather_rows(wc->c[l], wn->c[l], parent, N, dec->Hd * 4, stream));
+                MIC_TRY(mic_gather_rows(wc->xh[l], wn->xh[l], parent, N, dec->kpad[l] * sz, stream));
+            }
+        }
+        return 0;
+    };
+    if (!use_graph || t1 == t0) return body(stream);
+    return run_graphed(make_key("lstm_beam", *dec, ws[0], ws[1], st[0], st[1], parent, live_images, sqrt_tab, top_val, top_idx, B, K, t0,
+                                t1, t_cap, eos_id),
+                       (hipStream_t)stream, body);
+}
+
+// Steps [t0, t1) of batched greedy (u == NULL) or temperature sampling (u = uniforms [steps][N]) on one workspace.
+extern "C" int mic_lstm_sample_steps(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, int32_t* tokens, uint8_t* finished,
+                                     int32_t* live_rows, float inv_temp, const float* u, float* val, int32_t* idx, int t0, int t1,
+                                     int t_cap, int pad_id, int eos_id, int use_graph, void* stream) {
+    MIC_TRY(check_lstm_pair(dec, ws, 1, t0, t1, t_cap, "mic_lstm_sample_steps"));
+    MIC_ARG_CHECK(tokens && finished && live_rows && val && idx, "mic_lstm_sample_steps: null pointer");
+    const int N = ws->N;
+    auto body = [&](void* stream) -> int {
+        for (int t = t0; t < t1; ++t) {
+            MIC_TRY(mic_lstm_step(dec, ws, tokens, t_cap, t, nullptr, 0, stream));
+            if (u)
+                MIC_TRY(mic_sample_multinomial(ws->logits, dec->vocab, N, dec->vocab, inv_temp, u + (int64_t)t * N, val, idx, stream));
+            else
+                MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, N, dec->vocab, 1, 1.0f, 1, val, idx, nullptr, stream));
+            MIC_TRY(mic_sample_update(nullptr, idx, tokens, t_cap, t + 1, finished, nullptr, live_rows + t, N, pad_id, eos_id, stream));
+        }
+        return 0;
+    };
+    if (!use_graph || t1 == t0) return body(stream);
+    return run_graphed(make_key("lstm_samp", *dec, *ws, tokens, finished, live_rows, inv_temp, u, val, idx, t0, t1, t_cap, pad_id, eos_id),
+                       (hipStream_t)stream, body);
+}

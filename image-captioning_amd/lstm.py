@@ -22,13 +22,16 @@ from .vocabulary import EOS, PAD, SOS
 class ImageCaptioner:
     kind = None  # "basic" | "intermediate"
 
-    def __init__(self, vocab=None, dtype: torch.dtype = torch.bfloat16, encoder: str = "resnet50", sync_every: int = 8):
+    def __init__(self, vocab=None, dtype: torch.dtype = torch.bfloat16, encoder: str = "resnet50", sync_every: int = 8,
+                 use_graph: bool = True):
         if self.kind is None:
             raise TypeError("use BasicImageCaptioner or IntermediateImageCaptioner")
         if encoder not in ("resnet50", "none"):
             raise ValueError(f"Encoder {encoder} not recognized")
         self.vocab, self.dtype, self.encoder_kind = vocab, dtype, encoder
         self.sync_every = max(1, int(sync_every))
+        self.use_graph = bool(use_graph)  # replay each run of decode steps as one HIP graph
+        self._buffers = {}  # search buffers per shape: stable addresses keep the captured graphs valid
         self._sd, self.device, self.encoder, self.dec = None, None, None, None
 
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -60,6 +63,7 @@ class ImageCaptioner:
                 self._init_w = W.matrix(torch.cat([sd["decoder.init_h.weight"], sd["decoder.init_c.weight"]], 0), self.dtype, device)
                 self._init_b = W.vector(torch.cat([sd["decoder.init_h.bias"], sd["decoder.init_c.bias"]], 0), device)
         self.device = device
+        self._buffers = {}
         return self
 
     def eval(self):
@@ -127,44 +131,48 @@ class ImageCaptioner:
             f = torch.nn.functional.pad(f, (0, k - f.shape[1] % k))
         return f.contiguous()
 
+    def _trim_buffers(self, keep: int = 3):
+        while len(self._buffers) > keep:  # oldest shape first
+            self._buffers.pop(next(iter(self._buffers)))
+
     # ---- search -------------------------------------------------------------------------------
     def sample_ids(self, feats, max_len: int, temp: Optional[float], uniforms=None):
         """models/image_captioner.py:82-105 -> int32 tokens (B, n_tokens)."""
         feats = self._check_feats(feats)
         B, dev, dec = feats.shape[0], self.device, self.dec
-        ws, t, _ = self._new_ws(B)
-        self._init_state(feats, 1, ws, t)
         hot = not (temp is None or temp == 0.0)
         t_cap = max_len + 1
         pad, sos, eos = (self.vocab.str_to_idx(x) for x in (PAD, SOS, EOS))
-        tokens = torch.full((B, t_cap), pad, dtype=torch.int32, device=dev)
+        key = ("sample", B, t_cap)
+        if key not in self._buffers:
+            self._trim_buffers()
+            ws, t, _ = self._new_ws(B)
+            self._buffers[key] = (ws, t, torch.empty(B, t_cap, dtype=torch.int32, device=dev),
+                                  torch.empty(B, dtype=torch.uint8, device=dev), torch.empty(t_cap, dtype=torch.int32, device=dev),
+                                  torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                                  torch.empty(max_len, B, dtype=torch.float32, device=dev))
+        ws, t, tokens, finished, live, val, idx, ubuf = self._buffers[key]
+        self._init_state(feats, 1, ws, t)
+        tokens.fill_(pad)
         tokens[:, 0] = sos
-        finished = torch.zeros(B, dtype=torch.uint8, device=dev)
-        live = torch.zeros(t_cap, dtype=torch.int32, device=dev)
-        val = torch.empty(B, dtype=torch.float32, device=dev)
-        idx = torch.empty(B, dtype=torch.int32, device=dev)
-        u = None
+        finished.zero_()
+        live.zero_()
         if hot:
-            u = (uniforms if uniforms is not None else torch.rand(max_len, B, device=dev)).to(dev, torch.float32).contiguous()
+            ubuf.copy_(uniforms[:max_len] if uniforms is not None else torch.rand(max_len, B, device=dev))
         stream = L.stream_ptr()
-        done, chunk_start = max_len, 0
-        for s in range(max_len):
-            L.check(L.lib.mic_lstm_step(C.byref(dec), C.byref(ws), tokens.data_ptr(), t_cap, s, None, 0, stream), "mic_lstm_step")
-            if hot:
-                L.check(L.lib.mic_sample_multinomial(t["logits"].data_ptr(), dec.vocab, B, dec.vocab, 1.0 / temp, u[s].data_ptr(),
-                                                     val.data_ptr(), idx.data_ptr(), stream), "mic_sample_multinomial")
-            else:
-                L.check(L.lib.mic_logsoftmax_topk(t["logits"].data_ptr(), dec.vocab, B, dec.vocab, 1, 1.0, 1, val.data_ptr(),
-                                                  idx.data_ptr(), None, stream), "mic_logsoftmax_topk")
-            L.check(L.lib.mic_sample_update(None, idx.data_ptr(), tokens.data_ptr(), t_cap, s + 1, finished.data_ptr(), None,
-                                            live[s:].data_ptr(), B, pad, eos, stream), "mic_sample_update")
-            if (s + 1) % self.sync_every == 0 or s + 1 == max_len:
-                lv = live[chunk_start:s + 1].tolist()
-                if 0 in lv:  # the reference stops right after the step in which the last row finished
-                    done = chunk_start + lv.index(0) + 1
-                    break
-                chunk_start = s + 1
-        return tokens[:, : done + 1]
+        done, s = max_len, 0
+        while s < max_len:
+            e = min(max_len, s + self.sync_every)
+            L.check(L.lib.mic_lstm_sample_steps(C.byref(dec), C.byref(ws), tokens.data_ptr(), finished.data_ptr(), live.data_ptr(),
+                                                1.0 / temp if hot else 1.0, ubuf.data_ptr() if hot else None, val.data_ptr(),
+                                                idx.data_ptr(), s, e, t_cap, pad, eos, int(self.use_graph), stream),
+                    "mic_lstm_sample_steps")
+            lv = live[s:e].tolist()
+            if 0 in lv:  # the reference stops right after the step in which the last row finished
+                done = s + lv.index(0) + 1
+                break
+            s = e
+        return tokens[:, : done + 1].clone()
 
     def beam_search_ids(self, feats, max_len: int, beam_size: int):
         """models/image_captioner.py:118-159 -> int32 tokens (B, max_len+1) padded with -1, lengths (B,)."""
@@ -173,47 +181,44 @@ class ImageCaptioner:
         feats = self._check_feats(feats)
         B, dev, dec, K = feats.shape[0], self.device, self.dec, beam_size
         N, t_cap = B * K, max_len + 1
-        w0, t0_, shared = self._new_ws(N)
-        w1, t1_, _ = self._new_ws(N, shared)
-        wss, tts = [w0, w1], [t0_, t1_]
-        self._init_state(feats, K, w0, t0_)
         sos, eos = self.vocab.str_to_idx(SOS), self.vocab.str_to_idx(EOS)
-        st, keep = (L.BeamState * 2)(), []
-        for i in range(2):
-            score = torch.zeros(N, dtype=torch.float64, device=dev)
-            ln = torch.ones(N, dtype=torch.int32, device=dev)
-            seq = torch.full((N, t_cap), sos, dtype=torch.int32, device=dev)
-            keep.append((score, ln, seq))
-            st[i].score, st[i].len, st[i].seq, st[i].anc = score.data_ptr(), ln.data_ptr(), seq.data_ptr(), None
-        parent = torch.empty(N, dtype=torch.int32, device=dev)
-        live = torch.zeros(t_cap, dtype=torch.int32, device=dev)
-        top_val = torch.empty(N, K, dtype=torch.float32, device=dev)
-        top_idx = torch.empty(N, K, dtype=torch.int32, device=dev)
-        sqrt_tab = torch.tensor([float(i) ** 0.5 for i in range(t_cap + 2)], dtype=torch.float64).to(dev)
+        key = ("beam", B, K, t_cap)
+        if key not in self._buffers:
+            self._trim_buffers()
+            w0, t0_, shared = self._new_ws(N)
+            w1, t1_, _ = self._new_ws(N, shared)
+            wss = (L.LstmWorkspace * 2)(w0, w1)
+            st, keep = (L.BeamState * 2)(), []
+            for i in range(2):
+                score = torch.empty(N, dtype=torch.float64, device=dev)
+                ln = torch.empty(N, dtype=torch.int32, device=dev)
+                seq = torch.empty((N, t_cap), dtype=torch.int32, device=dev)
+                keep.append((score, ln, seq))
+                st[i].score, st[i].len, st[i].seq, st[i].anc = score.data_ptr(), ln.data_ptr(), seq.data_ptr(), None
+            sqrt_tab = torch.tensor([float(i) ** 0.5 for i in range(t_cap + 2)], dtype=torch.float64).to(dev)
+            self._buffers[key] = (wss, (t0_, t1_), st, keep, torch.empty(N, dtype=torch.int32, device=dev),
+                                  torch.empty(t_cap, dtype=torch.int32, device=dev), torch.empty(N, K, dtype=torch.float32, device=dev),
+                                  torch.empty(N, K, dtype=torch.int32, device=dev), sqrt_tab)
+        wss, tts, st, keep, parent, live, top_val, top_idx, sqrt_tab = self._buffers[key]
+        self._init_state(feats, K, wss[0], tts[0])
+        for score, ln, seq in keep:
+            score.zero_(); ln.fill_(1); seq.fill_(sos)
+        live.zero_()
         stream = L.stream_ptr()
-        sz = torch.empty((), dtype=self.dtype).element_size()
-        steps = 0
-        for s in range(max_len):
-            cur, nxt = s & 1, (s + 1) & 1
-            L.check(L.lib.mic_lstm_step(C.byref(dec), C.byref(wss[cur]), keep[cur][2].data_ptr(), t_cap, s, None, 0, stream), "mic_lstm_step")
-            L.check(L.lib.mic_logsoftmax_topk(shared["logits"].data_ptr(), dec.vocab, N, dec.vocab, K, 1.0, 0, top_val.data_ptr(),
-                                              top_idx.data_ptr(), None, stream), "mic_logsoftmax_topk")
-            L.check(L.lib.mic_beam_select(C.byref(st[cur]), C.byref(st[nxt]), top_val.data_ptr(), top_idx.data_ptr(), parent.data_ptr(),
-                                          live[s:].data_ptr(), sqrt_tab.data_ptr(), B, K, 1 if s == 0 else K, s, t_cap, eos, 1, stream),
-                    "mic_beam_select")
-            for l in range(dec.layers):  # survivors inherit their parent's recurrent state
-                for name, rb in (("h", dec.Hd * 4), ("c", dec.Hd * 4), ("xh", dec.kpad[l] * sz)):
-                    L.check(L.lib.mic_gather_rows(tts[cur][name][l].data_ptr(), tts[nxt][name][l].data_ptr(), parent.data_ptr(), N, rb,
-                                                  stream), "mic_gather_rows")
-            steps = s + 1
-            if steps % self.sync_every == 0 and steps < max_len and int(live[s].item()) == 0:
+        steps, s = 0, 0
+        while s < max_len:
+            e = min(max_len, s + self.sync_every)
+            L.check(L.lib.mic_lstm_beam_steps(C.byref(dec), wss, st, parent.data_ptr(), live.data_ptr(), sqrt_tab.data_ptr(),
+                                              top_val.data_ptr(), top_idx.data_ptr(), B, K, s, e, t_cap, eos, int(self.use_graph),
+                                              stream), "mic_lstm_beam_steps")
+            steps = s = e
+            if e < max_len and int(live[e - 1].item()) == 0:
                 break
         tokens = torch.empty(B, t_cap, dtype=torch.int32, device=dev)
         lengths = torch.empty(B, dtype=torch.int32, device=dev)
         score = torch.empty(B, dtype=torch.float32, device=dev)
         L.check(L.lib.mic_beam_finalize(C.byref(st[steps & 1]), sqrt_tab.data_ptr(), B, K, t_cap, tokens.data_ptr(), lengths.data_ptr(),
                                         score.data_ptr(), None, 0, None, stream), "mic_beam_finalize")
-        self._keep_alive = (keep, wss, tts)
         return tokens, lengths
 
     # ---- reference-compatible API -------------------------------------------------------------

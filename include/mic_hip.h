@@ -496,6 +496,20 @@ typedef struct mic_lstm_workspace {
 int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, const int32_t* tokens, int ld_tok,
                   int pos, const void* feat_t, int ld_feat, void* stream);
 
+/* Steps [t0, t1) of LSTM beam search (models/image_captioner.py:118-159).  Step t runs on ws[t & 1]; the
+ * survivors' h, c and [x | h] rows are gathered by parent into ws[(t + 1) & 1]; st as in mic_tr_beam_steps
+ * (anc unused), seq rows hold t_cap tokens.  top_val/top_idx: [B*K][K] scratch.  With use_graph the run is
+ * captured once per argument set and replayed. */
+int mic_lstm_beam_steps(const mic_lstm_decoder* dec, const mic_lstm_workspace ws[2], const mic_beam_state st[2],
+                        int32_t* parent, int32_t* live_images, const double* sqrt_tab, float* top_val, int32_t* top_idx,
+                        int B, int K, int t0, int t1, int t_cap, int eos_id, int use_graph, void* stream);
+
+/* Steps [t0, t1) of batched greedy (u == NULL) or temperature sampling (u = uniforms [steps][N]) with an
+ * LSTM decoder (models/image_captioner.py:82-105).  val/idx: [N] scratch; tokens [N][t_cap]. */
+int mic_lstm_sample_steps(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, int32_t* tokens, uint8_t* finished,
+                          int32_t* live_rows, float inv_temp, const float* u, float* val, int32_t* idx, int t0, int t1,
+                          int t_cap, int pad_id, int eos_id, int use_graph, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
