@@ -33,6 +33,9 @@ WORKLOADS = {
                         "beam=3, max_len=30, 224x224, batch 256 per GPU, bf16; random-init weights"),
     "swin": dict(batch=512, beam=5, label="configs[3]: Swin-V2-S encoder + 3-layer transformer decoder (H=512, 2 heads, V=3500), beam=5, "
                  "max_len=30, 224x224, batch 512 per GPU, bf16; random-init weights"),
+    "swin_t": dict(batch=512, beam=5, label="configs[3] as worded: Swin-V2-T encoder (depths 2,2,6,2; the reference itself builds swin_v2_s, "
+                   "which is --workload swin) + 3-layer transformer decoder (H=512, 2 heads, V=3500), beam=5, max_len=30, 224x224, "
+                   "batch 512 per GPU, bf16; random-init weights"),
     "lstm": dict(batch=64, beam=3, label="configs[1]: ResNet-50 encoder + 2-layer LSTM decoder (intermediate model, E=H=512, V=3500), "
                  "beam=3, max_len=30, 224x224, batch 64 per GPU, bf16; random-init weights"),
 }
@@ -40,8 +43,8 @@ WORKLOADS = {
 
 def build_state(workload: str = "transformer"):
     import image_captioning_amd as amd
-    if workload == "swin":
-        sd = amd.weights.random_swin_state(0)
+    if workload in ("swin", "swin_t"):
+        sd = amd.weights.random_swin_state(0, depths=(2, 2, 6, 2) if workload == "swin_t" else (2, 2, 18, 2))
         sd.update(amd.weights.random_head_state("swin", H, 0, in_dim=768))
     elif workload == "lstm":
         sd = amd.weights.random_resnet50_state(0)
@@ -68,7 +71,7 @@ def cpu_baseline(sd, n_images: int, workload: str, beam: int):
         if workload == "lstm":
             O.lstm_generate(sd, "intermediate", O.encoder_intermediate(sd, img), MAX_LEN, None, beam)
         else:
-            feats = (O.encoder_swin if workload == "swin" else O.encoder_transformer)(sd, img)
+            feats = (O.encoder_swin if workload in ("swin", "swin_t") else O.encoder_transformer)(sd, img)
             O.transformer_generate(sd, HEADS, feats, MAX_LEN, None, beam)
     dt = time.perf_counter() - t0
     return {"value": round(n_images / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
@@ -123,7 +126,7 @@ def main():
     if args.workload == "lstm":
         model = amd.lstm.IntermediateImageCaptioner(vocab, torch.bfloat16, sync_every=MAX_LEN).load_state_dict(sd).to(dev)
     else:
-        model = amd.transformer.ImageCaptioner(vocab, HEADS, torch.bfloat16, encoder="swin" if args.workload == "swin" else "resnet50",
+        model = amd.transformer.ImageCaptioner(vocab, HEADS, torch.bfloat16, encoder="swin" if args.workload in ("swin", "swin_t") else "resnet50",
                                                sync_every=MAX_LEN, decode_groups=args.decode_groups).load_state_dict(sd).to(dev)
     B = args.batch or wl["batch"]
     images = torch.randn(B, 3, IMG, IMG, generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev)
