@@ -79,6 +79,28 @@ def cpu_baseline(sd, n_images: int, workload: str, beam: int):
                       f"recompute, fp32 torch CPU), {dt:.1f} s"}
 
 
+HBM_PEAK_TBS = 8.0  # HBM3E peak of one MI355X
+
+
+def decode_roofline(ms: float, batch: int, beam: int, steps: int, S: int):
+    """Algorithmic bytes of one beam search at bf16 (2 bytes) over `steps` executed steps, N = batch*beam rows:
+    per step the decoder weights once (8 H^2 per layer: packed self in-projection 3, self out-projection 1,
+    feed-forward 4; the cross-attention projections are folded into the per-image keys/values) plus the vocabulary
+    matrix; the folded cross-attention keys and values of every image and layer (heads x the unfolded size); the
+    self-attention cache (read positions 0..t of every row, write one); logits written and read in fp32; and once
+    per search the cross-K/V projection (image tokens read, folded keys/values written)."""
+    N, e = batch * beam, 2
+    weights = (LAYERS * 8 * H * H + V * H) * e
+    folded = LAYERS * 2 * batch * S * HEADS * H * e
+    cache = sum(LAYERS * 2 * N * H * e * (t + 1) for t in range(steps))  # t reads + 1 write at step t
+    logits = 2 * N * V * 4
+    once = batch * S * H * e + folded
+    total = steps * (weights + folded + logits) + cache + once
+    tbs = total / (ms * 1e-3) / 1e12
+    return {"bound": "hbm", "phase": "cross-K/V + beam steps + best-beam extraction", "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS,
+            "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4), "ms": round(ms, 3), "algorithmic_bytes": int(total)}
+
+
 def measured_traffic():
     """HBM bytes per launch of the 128-row-tile bf16 igemm kernels on this workload, from the committed
     rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs of this script; a live
@@ -164,6 +186,18 @@ def main():
         elapsed = float(t.item())
     executed_steps = int(out[1].max().item()) - 1  # generated tokens of the longest caption
 
+    decode = None
+    if rank == 0 and args.workload == "transformer":  # the byte count below is that of the folded, chained decode path
+        # the search alone (cross-K/V + beam steps + best-beam extraction) between two events on the launch
+        # stream, outside the timed region, priced against HBM bandwidth by its algorithmic bytes
+        feats = model.encode(images)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        model.beam_search_ids(feats, MAX_LEN, beam)
+        e1.record()
+        torch.cuda.synchronize()
+        decode = decode_roofline(e0.elapsed_time(e1), B, beam, executed_steps, feats.shape[1])
+
     if rank == 0:
         # dominant kernel: igemm_kernel<bf16,128,128> (slot 1), the encoder's implicit-GEMM convolutions
         k_ms, k_n, k_fl = ms[1], cnt[1], fl[1]
@@ -183,6 +217,8 @@ def main():
                          "gflop_per_launch": round(k_fl / k_n / 1e9, 3) if k_n else None,
                          "other_gemm_launches": {"igemm<bf16,64-row tiles>": {"n": cnt[3], "ms": round(ms[3], 3), "tflops": round(fl[3] / (ms[3] * 1e-3) / 1e12, 2) if ms[3] else None}}},
         }
+        if decode is not None:
+            res["roofline_decode"] = decode
         if args.cpu_images > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline(sd, args.cpu_images, args.workload, beam)
         print(json.dumps(res), flush=True)
