@@ -209,7 +209,8 @@ __device__ __forceinline__ void merge_row_stats(const LnRef& l, int m, float& me
 // round trips to L2 with 8 fragment loads in flight, so eight waves of one tile each finish it in half
 // the round trips of four waves of two.
 template <typename T, int MT, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : 1) void skinny_gemm_kernel(const SkinnyArgs a) {
+// (the second launch bound is waves per SIMD: 4 keeps two 8-wave workgroups on a CU, i.e. at most 128 registers per lane)
+__global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : (MT == 1 && NWV == 8) ? 4 : 1) void skinny_gemm_kernel(const SkinnyArgs a) {
     constexpr int VEC = 16 / (int)sizeof(T), EPR = 4 * VEC, TPW = 8 / NWV, U = (MT >= 4 ? 4 : 8) / TPW, ROWS = MT * 16;
     constexpr int NT = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
