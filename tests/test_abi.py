@@ -88,8 +88,32 @@ def test_argument_errors_need_no_gpu():
     assert L.lib.mic_swin_workspace_bytes(C.byref(sw), 8, 224, 224) == -1  # 384 channels need 12 heads of 32
     assert L.lib.mic_window_attn(None, None, None, None, None, 0, 1, 8, 8, 32, 1, 0, None) == -1
     assert L.lib.mic_patchify4(None, None, 0, 1, 8, 8, None) == -1
+    # the graph-replayed LSTM search drivers validate before they touch the device
+    assert L.lib.mic_lstm_beam_steps(None, None, None, None, None, None, None, None, 1, 3, 0, 1, 8, 2, 1, None) == -1
+    dec, wss, st = L.LstmDecoder(), (L.LstmWorkspace * 2)(), (L.BeamState * 2)()
+    wss[0].N = wss[1].N = 6
+    wss[0].logits = wss[1].logits = 16
+    assert L.lib.mic_lstm_beam_steps(C.byref(dec), wss, st, None, None, None, None, None, 2, 3, 0, 9, 8, 2, 1, None) == -1
+    assert b"do not fit t_cap" in L.lib.mic_last_error()
+    assert L.lib.mic_lstm_beam_steps(C.byref(dec), wss, st, 16, 16, 16, 16, 16, 2, 4, 0, 1, 8, 2, 1, None) == -1
+    assert b"B*K" in L.lib.mic_last_error()
+    assert L.lib.mic_lstm_sample_steps(C.byref(dec), wss, None, None, None, 1.0, None, None, None, 0, 1, 8, 0, 2, 1, None) == -1
     with pytest.raises(L.MicError, match="argument error"):
         L.check(-1, "probe")
+
+
+def test_decode_roofline_bytes():
+    """bench.py's search-phase byte count, term by term, at the headline configuration."""
+    import bench
+    r = bench.decode_roofline(8.0, 256, 3, 30, 49)
+    N, H, V, Lr, e = 768, 512, 3500, 3, 2
+    weights = (Lr * 8 * H * H + V * H) * e
+    folded = Lr * 2 * 256 * 49 * 2 * H * e
+    cache = Lr * 2 * N * H * e * sum(range(1, 31))
+    logits = 2 * N * V * 4
+    total = 30 * (weights + folded + logits) + cache + 256 * 49 * H * e + folded
+    assert r["algorithmic_bytes"] == total
+    assert r["unit"] == "TB/s" and abs(r["achieved"] - total / 8e-3 / 1e12) < 1e-3 and r["frac"] == round(r["achieved"] / 8.0, 4)
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
