@@ -8,7 +8,7 @@ with ``weights_only=True``: nothing in it is executed.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

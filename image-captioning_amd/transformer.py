@@ -9,9 +9,8 @@ re-running the prefix, beam bookkeeping on the device in fp64.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional
+from typing import Optional
 
-import numpy as np
 import torch
 
 from . import _lib as L

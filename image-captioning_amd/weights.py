@@ -7,7 +7,6 @@ folded into the convolution, fp32 biases / LayerNorm / embedding tables.  Load-t
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Dict, List, Optional, Sequence
 

@@ -7,7 +7,6 @@ attention with index-mapped padding / shift / masking, GELU epilogue, patch merg
 implicit GEMM, residual-post-norm) computes the same function as that restatement.
 fp32: 1e-3 of the feature scale.  bf16: relative L2 error below 3e-2 (tiny) / 5e-2 (24 blocks).
 """
-import ctypes as C
 
 import numpy as np
 import pytest
