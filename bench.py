@@ -135,9 +135,12 @@ def main():
     import image_captioning_amd as amd
     from image_captioning_amd import distributed as D
 
-    rank, local, world = D.init_from_env("nccl")
+    # RCCL ("nccl") is the backend of every real run; MIC_DIST_BACKEND=gloo lets the multi-rank control flow be
+    # rehearsed on a box with fewer GPUs than ranks (ranks then share devices round-robin)
+    backend = os.environ.get("MIC_DIST_BACKEND", "nccl")
+    rank, local, world = D.init_from_env(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local if backend == "nccl" else local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     L = amd._lib
 

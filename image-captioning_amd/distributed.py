@@ -63,15 +63,17 @@ def gather_captions(tokens: torch.Tensor, lengths: torch.Tensor, scores: torch.T
         buf = torch.empty(world * per, T + 2, dtype=torch.int32, device=pack.device)
         if dist.get_backend() == "nccl":
             dist.all_gather_into_tensor(buf, pack)
-        else:
-            parts = [torch.empty_like(pack) for _ in range(world)]
-            dist.all_gather(parts, pack)
-            buf = torch.cat(parts, dim=0)
+        else:  # gloo gathers host tensors
+            host = pack.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host)
+            buf = torch.cat(parts, dim=0).to(pack.device)
     else:
-        parts = [torch.empty_like(pack) for _ in range(world)] if rank == dst else None
-        dist.gather(pack, parts, dst=dst)
+        src = pack if dist.get_backend() == "nccl" else pack.cpu()
+        parts = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+        dist.gather(src, parts, dst=dst)
         if rank != dst:
             return None, None, None
-        buf = torch.cat(parts, dim=0)
+        buf = torch.cat(parts, dim=0).to(pack.device)
     buf = buf[:n_total]
     return buf[:, :T].contiguous(), buf[:, T].contiguous(), buf[:, T + 1].contiguous().view(torch.float32)
