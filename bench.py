@@ -8,7 +8,11 @@ images, batch 256 per GPU, bf16 weights/GEMM inputs with fp32 accumulation.
 One "step" = one whole generate call (encoder + cross-K/V + 30 beam-search steps + best-beam
 extraction) over one batch of 256 images that already sit in HBM, followed by the gather of token
 ids across ranks.  String detokenisation is excluded (the metric is defined on token ids).
-Prints ONE JSON line on rank 0.
+The timed region runs the batches one after another, so that the per-kernel durations behind the
+roofline figures are those of kernels that have the GPU to themselves.  Batches are independent, so a
+job can keep several in flight (--lanes N: one host thread, stream and set of workspaces per lane,
+image_captioning_amd/lanes.py); the throughput of 3 lanes is measured after the timed region and
+reported as "concurrent_lanes".  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
@@ -118,6 +122,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--lanes", type=int, default=1, help="whole batches in flight per GPU in the timed region (host threads with a stream "
+                    "and workspaces each); with 1, the throughput of 3 lanes is measured after the timed region and reported beside it")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
     ap.add_argument("--decode-groups", type=int, default=1, help="concurrent beam-search sub-batches per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="transformer")
@@ -157,14 +163,25 @@ def main():
     images = torch.randn(B, 3, IMG, IMG, generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev)
     n_total = B * world
 
-    def step():
-        feats = model.encoder(images) if args.workload == "lstm" else model.encode(images)
+    n_lanes = max(1, args.lanes)
+    lanes = amd.lanes.Lanes(model, max(3, n_lanes))  # one pool: more streams than hardware queues would make lanes take turns
+
+    def caption(m, _item):
+        feats = m.encoder(images) if args.workload == "lstm" else m.encode(images)
         if args.workload == "lstm":
-            tokens, lengths = model.beam_search_ids(feats, MAX_LEN, beam)
+            tokens, lengths = m.beam_search_ids(feats, MAX_LEN, beam)
             score = torch.zeros(B, device=dev)  # models/image_captioner.py:61-69 returns no scores
         else:
-            tokens, lengths, score, _ = model.beam_search_ids(feats, MAX_LEN, beam)
-        return D.gather_captions(tokens, lengths, score, n_total)
+            tokens, lengths, score, _ = m.beam_search_ids(feats, MAX_LEN, beam)
+        return tokens, lengths, score
+
+    def run_steps(n, in_flight=n_lanes):
+        """n steps = n whole batches through encoder + search, at most `in_flight` of them at a time; then, in step order
+        on this thread, the gather of every step's ids across ranks."""
+        out = None
+        for tokens, lengths, score in lanes.map(caption, range(n), in_flight):
+            out = D.gather_captions(tokens, lengths, score, n_total)
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -172,13 +189,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
+    run_steps(len(lanes), len(lanes))  # set-up, not a step: every lane allocates its workspaces and captures its graphs
+    run_steps(args.warmup)
     fence()
     L.check(L.lib.mic_profile_begin(max(1, args.steps) * 1200), "mic_profile_begin")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     cnt, ms, fl = (C.c_int32 * 4)(), (C.c_double * 4)(), (C.c_double * 4)()
@@ -188,6 +204,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     executed_steps = int(out[1].max().item()) - 1  # generated tokens of the longest caption
+
+    concurrent = None
+    if world == 1 and n_lanes == 1:
+        # throughput with three whole batches in flight, outside the timed region: the timed region stays one batch at a
+        # time so that its per-kernel durations are those of a kernel that has the GPU to itself
+        n3 = max(12, args.steps)
+        run_steps(3, 3)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        run_steps(n3, 3)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - ts
+        concurrent = {"lanes": 3, "steps": n3, "value": round(B * n3 / dt3, 2), "unit": "images/s", "ms_per_step": round(dt3 / n3 * 1e3, 3)}
+
+    single = None
+    if rank == 0 and n_lanes > 1:
+        # the same kernels with the GPU to themselves: under concurrent lanes a launch's duration includes the other
+        # lanes' work, so the per-kernel reading is taken again on one lane, outside the timed region
+        run_steps(1, 1)
+        torch.cuda.synchronize()
+        L.check(L.lib.mic_profile_begin(3 * 1200), "mic_profile_begin")
+        ts = time.perf_counter()
+        run_steps(3, 1)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - ts) / 3 * 1e3
+        c1, m1, f1 = (C.c_int32 * 4)(), (C.c_double * 4)(), (C.c_double * 4)()
+        L.check(L.lib.mic_profile_end(c1, m1, f1), "mic_profile_end")
+        single = (c1[1], m1[1], f1[1], single_ms)
 
     decode = None
     if rank == 0 and args.workload == "transformer":  # the byte count below is that of the folded, chained decode path
@@ -202,16 +246,22 @@ def main():
         decode = decode_roofline(e0.elapsed_time(e1), B, beam, executed_steps, feats.shape[1])
 
     if rank == 0:
-        # dominant kernel: igemm_kernel<bf16,128,128> (slot 1), the encoder's implicit-GEMM convolutions
+        # dominant kernel: igemm_kernel<bf16> with tiles of 128 rows and more (slot 1), the encoder's implicit-GEMM convolutions
         k_ms, k_n, k_fl = ms[1], cnt[1], fl[1]
         achieved = (k_fl / k_n) / (k_ms / k_n * 1e-3) / 1e12 if k_n else 0.0
+
+        def igemm_roofline(n, t_ms, flops):
+            tf = flops / (t_ms * 1e-3) / 1e12 if n else 0.0
+            return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_us": round(t_ms / n * 1e3, 2) if n else None}
         res = {
             "metric": f"images captioned/sec (224^2, beam={beam}, max_len=30)", "value": round(n_total * args.steps / elapsed, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl["label"] if B == wl["batch"] else wl["label"].replace(f"batch {wl['batch']}", f"batch {B}"),
-                       "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}"},
+                       "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}",
+                       "lanes_per_gpu": n_lanes},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16> (all tile variants of 128 rows and more)", "achieved": round(achieved, 2),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                          "traffic": measured_traffic() if args.workload == "transformer" and B == BATCH else None, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
@@ -220,6 +270,13 @@ def main():
                          "gflop_per_launch": round(k_fl / k_n / 1e9, 3) if k_n else None,
                          "other_gemm_launches": {"igemm<bf16,64-row tiles>": {"n": cnt[3], "ms": round(ms[3], 3), "tflops": round(fl[3] / (ms[3] * 1e-3) / 1e12, 2) if ms[3] else None}}},
         }
+        if single is not None:
+            res["roofline"]["note"] = (f"launch durations in the timed region, {n_lanes} batches in flight: a launch shares the GPU with "
+                                       "the other lanes' kernels; roofline_single_lane is the same kernel with the GPU to itself")
+            res["roofline_single_lane"] = dict(igemm_roofline(*single[:3]), ms_per_step=round(single[3], 3),
+                                               images_per_s=round(B / (single[3] * 1e-3), 1))
+        if concurrent is not None:
+            res["concurrent_lanes"] = concurrent
         if decode is not None:
             res["roofline_decode"] = decode
         if args.cpu_images > 0 and world == 1:

@@ -13,6 +13,6 @@ All compute goes through csrc/libmic_hip.so (include/mic_hip.h); importing fails
 from . import _lib  # noqa: F401  (loads libmic_hip.so or raises)
 from .captioner import gen_caption
 from .vocabulary import Vocabulary, PAD, SOS, EOS, UNK
-from . import transformer, lstm, encoders, weights, checkpoint, preprocess
+from . import transformer, lstm, encoders, weights, checkpoint, preprocess, lanes
 
-__all__ = ["gen_caption", "Vocabulary", "transformer", "lstm", "encoders", "weights", "checkpoint", "preprocess", "PAD", "SOS", "EOS", "UNK"]
+__all__ = ["gen_caption", "Vocabulary", "transformer", "lstm", "encoders", "weights", "checkpoint", "preprocess", "lanes", "PAD", "SOS", "EOS", "UNK"]

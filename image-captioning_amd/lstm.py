@@ -69,6 +69,18 @@ class ImageCaptioner:
     def eval(self):
         return self
 
+    def lane_copy(self):
+        """A second handle on the same device weights with buffers of its own, for a concurrent lane (lanes.Lanes)."""
+        import copy
+        if self.device is None:
+            raise RuntimeError("lane_copy() needs a model that is on its device")
+        m = copy.copy(self)
+        m._buffers = {}
+        if self.encoder is not None:
+            m.encoder = copy.copy(self.encoder)
+            m.encoder._ws = None
+        return m
+
     @classmethod
     def from_state_dict(cls, state_dict, vocab=None, dtype=torch.bfloat16, device="cuda", encoder: Optional[str] = None, **kw):
         if encoder is None:

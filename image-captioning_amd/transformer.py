@@ -89,6 +89,18 @@ class ImageCaptioner:
     def eval(self):
         return self
 
+    def lane_copy(self):
+        """A second handle on the same device weights with workspaces of its own, for a concurrent lane (lanes.Lanes)."""
+        import copy
+        if self.device is None:
+            raise RuntimeError("lane_copy() needs a model that is on its device")
+        m = copy.copy(self)
+        m._ws_cache, m._side_streams = {}, []
+        if self.encoder is not None:
+            m.encoder = copy.copy(self.encoder)
+            m.encoder._ws = None
+        return m
+
     # ---- workspace ----------------------------------------------------------------------------
     def _workspace(self, N: int, t_cap: int, S: int, rpi: int, K: int, attn_mode: int, slot: int = 0):
         key = (N, t_cap, S, rpi, K, attn_mode, slot)

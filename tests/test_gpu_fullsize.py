@@ -179,3 +179,27 @@ def test_lstm_full_size_bf16_against_fp32_oracle_on_a_sample(amd):
             mine = [int(v) for v in tokens[b, : int(lengths[b])].cpu()]
             a, r = normalised(feats[b:b + 1], mine), normalised(feats[b:b + 1], best[b])
             assert abs(a - r) < 1e-2 * abs(r), (b, a, r, mine, best[b])
+
+
+def test_concurrent_lanes_reproduce_sequential_results(amd):
+    """Three whole batches in flight (lanes.Lanes: one host thread, stream and set of workspaces per lane, shared weights)
+    must give, batch by batch, the bits of running the batches one after another."""
+    wl = bench.WORKLOADS["transformer"]
+    model = amd.transformer.ImageCaptioner(amd.Vocabulary.synthetic(bench.V), bench.HEADS, torch.bfloat16, encoder="resnet50",
+                                           sync_every=bench.MAX_LEN).load_state_dict(bench.build_state("transformer")).to(DEV)
+    batches = [_images(wl["batch"], seed) for seed in (11, 12, 13, 14, 15)]
+
+    def caption(m, images):
+        tokens, lengths, score, _ = m.beam_search_ids(m.encode(images), bench.MAX_LEN, wl["beam"])
+        return tokens.clone(), lengths.clone(), score.clone()
+
+    one_by_one = [caption(model, b) for b in batches]
+    lanes = amd.lanes.Lanes(model, 3)
+    assert len(lanes) == 3 and lanes.models[1].dec is model.dec and lanes.models[1].encoder is not model.encoder
+    for _ in range(2):  # the second pass runs on warm lanes (captured graphs, allocated workspaces)
+        in_flight = lanes.map(caption, batches)
+        for a, b in zip(one_by_one, in_flight):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+    with pytest.raises(ZeroDivisionError):  # a lane's exception surfaces on the caller
+        lanes.map(lambda m, item: 1 // item, [1, 0, 2])
