@@ -126,6 +126,8 @@ def main():
                     "and workspaces each); with 1, the throughput of 3 lanes is measured after the timed region and reported beside it")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
     ap.add_argument("--decode-groups", type=int, default=1, help="concurrent beam-search sub-batches per GPU")
+    ap.add_argument("--concurrent-steps", type=int, default=12, help="steps of the 3-lane throughput measurement that follows the timed "
+                    "region at --lanes 1 (0 skips it, e.g. under a profiler, so that the kernel statistics are those of the timed region's schedule)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="transformer")
     ap.add_argument("--cpu-images", type=int, default=128, help="sample size of the CPU baseline (0 disables it)")
     args = ap.parse_args()
@@ -164,7 +166,8 @@ def main():
     n_total = B * world
 
     n_lanes = max(1, args.lanes)
-    lanes = amd.lanes.Lanes(model, max(3, n_lanes))  # one pool: more streams than hardware queues would make lanes take turns
+    # one pool for the timed region and the 3-lane measurement: more streams than hardware queues would make lanes take turns
+    lanes = amd.lanes.Lanes(model, max(3, n_lanes) if args.concurrent_steps > 0 else n_lanes)
 
     def caption(m, _item):
         feats = m.encoder(images) if args.workload == "lstm" else m.encode(images)
@@ -206,10 +209,10 @@ def main():
     executed_steps = int(out[1].max().item()) - 1  # generated tokens of the longest caption
 
     concurrent = None
-    if world == 1 and n_lanes == 1:
+    if world == 1 and n_lanes == 1 and args.concurrent_steps > 0:
         # throughput with three whole batches in flight, outside the timed region: the timed region stays one batch at a
         # time so that its per-kernel durations are those of a kernel that has the GPU to itself
-        n3 = max(12, args.steps)
+        n3 = args.concurrent_steps
         run_steps(3, 3)
         torch.cuda.synchronize()
         ts = time.perf_counter()
