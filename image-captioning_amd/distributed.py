@@ -77,3 +77,40 @@ def gather_captions(tokens: torch.Tensor, lengths: torch.Tensor, scores: torch.T
         buf = torch.cat(parts, dim=0).to(pack.device)
     buf = buf[:n_total]
     return buf[:, :T].contiguous(), buf[:, T].contiguous(), buf[:, T + 1].contiguous().view(torch.float32)
+
+
+def caption_dataset(model, caption, make_batch, n_total: int, n_tokens: int, batch: int = 256, lanes: int = 1):
+    """Caption items 0..n_total-1 data-parallel: this rank takes its contiguous slice (shard_range), walks it in
+    micro-batches of `batch`, and every rank returns the gathered (tokens int32 (n_total, n_tokens), lengths, scores)
+    in item order.  `make_batch(lo, hi)` returns the input of items [lo, hi) on the model's device;
+    `caption(model, input)` returns (tokens (n, n_tokens) int32, lengths (n,), scores (n,)).  With lanes > 1 that
+    many micro-batches are in flight on the GPU at once (lanes.Lanes); the result does not depend on it.
+    No collective runs before the final gather."""
+    if n_total < 0 or batch < 1 or n_tokens < 1:
+        raise ValueError(f"bad sizes n_total={n_total} batch={batch} n_tokens={n_tokens}")
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    lo, hi = shard_range(n_total, rank, world)
+    spans = [(a, min(hi, a + batch)) for a in range(lo, hi, batch)]
+
+    def work(m, span):
+        tokens, lengths, scores = caption(m, make_batch(*span))
+        return tokens.clone(), lengths.clone(), scores.clone()  # a model may hand out views of buffers it reuses
+
+    if lanes > 1 and len(spans) > 1:
+        from .lanes import Lanes
+        parts = Lanes(model, lanes).map(work, spans)
+    else:
+        parts = [work(model, s) for s in spans]
+    if parts:
+        tokens = torch.cat([p[0] for p in parts]).to(torch.int32)
+        lengths = torch.cat([p[1] for p in parts]).to(torch.int32)
+        scores = torch.cat([p[2] for p in parts]).to(torch.float32)
+    else:  # more ranks than micro-batches: an empty shard still takes part in the gather
+        dev = getattr(model, "device", None) or "cpu"
+        tokens = torch.empty(0, n_tokens, dtype=torch.int32, device=dev)
+        lengths = torch.empty(0, dtype=torch.int32, device=dev)
+        scores = torch.empty(0, dtype=torch.float32, device=dev)
+    if tokens.shape[1] != n_tokens:
+        raise ValueError(f"caption() returned {tokens.shape[1]} tokens per item, expected {n_tokens}")
+    return gather_captions(tokens, lengths, scores, n_total)

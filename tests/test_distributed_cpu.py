@@ -33,6 +33,17 @@ def _worker(rank, world, port, n_total, q):
     scores = -idx.float()
     out_all = D.gather_captions(tokens, lengths, scores, n_total)
     out_dst = D.gather_captions(tokens, lengths, scores, n_total, dst=0)
+    # the whole job: micro-batches of 3 over this rank's slice, one gather at the end; then a job with fewer items than ranks
+    class Host:
+        device = None
+
+    def caption(_model, ix):
+        return (ix[:, None] * 10 + torch.arange(T)[None]).to(torch.int32), (ix % T + 1).to(torch.int32), -ix.float()
+
+    job = D.caption_dataset(Host(), caption, lambda a, b: torch.arange(a, b), n_total, T, batch=3)
+    assert all(torch.equal(x, y) for x, y in zip(job, out_all))
+    tiny = D.caption_dataset(Host(), caption, lambda a, b: torch.arange(a, b), 1, T, batch=3)
+    assert tiny[0].tolist() == [[t for t in range(T)]] and tiny[1].tolist() == [1]
     q.put((rank, [t.tolist() for t in out_all], None if out_dst[0] is None else [t.tolist() for t in out_dst]))
     dist.barrier()
     dist.destroy_process_group()

@@ -203,3 +203,29 @@ def test_concurrent_lanes_reproduce_sequential_results(amd):
                 assert torch.equal(x, y)
     with pytest.raises(ZeroDivisionError):  # a lane's exception surfaces on the caller
         lanes.map(lambda m, item: 1 // item, [1, 0, 2])
+
+
+def test_caption_dataset_job_is_lane_invariant(amd):
+    """distributed.caption_dataset (the sharded whole-job driver; one rank here) over 768 synthetic images in micro-batches
+    of 256: three micro-batches in flight give the bits of one at a time, in item order."""
+    from image_captioning_amd import distributed as D
+
+    wl = bench.WORKLOADS["transformer"]
+    model = amd.transformer.ImageCaptioner(amd.Vocabulary.synthetic(bench.V), bench.HEADS, torch.bfloat16, encoder="resnet50",
+                                           sync_every=bench.MAX_LEN).load_state_dict(bench.build_state("transformer")).to(DEV)
+
+    def make_batch(lo, hi):  # images are a function of the global index of their micro-batch, not of who computes them
+        return torch.randn(hi - lo, 3, bench.IMG, bench.IMG, generator=torch.Generator(device=DEV).manual_seed(1000 + lo), device=DEV)
+
+    def caption(m, images):
+        tokens, lengths, score, _ = m.beam_search_ids(m.encode(images), bench.MAX_LEN, wl["beam"])
+        return tokens, lengths, score
+
+    n = 3 * wl["batch"]
+    one = D.caption_dataset(model, caption, make_batch, n, bench.MAX_LEN + 1, batch=wl["batch"], lanes=1)
+    three = D.caption_dataset(model, caption, make_batch, n, bench.MAX_LEN + 1, batch=wl["batch"], lanes=3)
+    assert one[0].shape == (n, bench.MAX_LEN + 1)
+    for a, b in zip(one, three):
+        assert torch.equal(a, b)
+    first = caption(model, make_batch(0, wl["batch"]))
+    assert torch.equal(first[0], one[0][: wl["batch"]])
