@@ -167,7 +167,7 @@ def main():
 
     n_lanes = max(1, args.lanes)
     # one pool for the timed region and the 3-lane measurement: more streams than hardware queues would make lanes take turns
-    lanes = amd.lanes.Lanes(model, max(3, n_lanes) if args.concurrent_steps > 0 else n_lanes)
+    lanes = amd.lanes.Lanes(model, max(3, n_lanes) if args.concurrent_steps > 0 and world == 1 else n_lanes)
 
     def caption(m, _item):
         feats = m.encoder(images) if args.workload == "lstm" else m.encode(images)
