@@ -501,7 +501,7 @@ int check_lstm_pair(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, i
 }  // namespace
 
 // Steps [t0, t1) of LSTM beam search.  Step t runs on workspace t & 1; the survivors' recurrent state
-// (h, c and the [x | h] GEMM input of every layer) is gathered by parent row into workspace (t + 1) & 1.
+// (c and the [x | h] GEMM input of every layer) is gathered by parent row into workspace (t + 1) & 1.
 extern "C" int mic_lstm_beam_steps(const mic_lstm_decoder* dec, const mic_lstm_workspace ws[2], const mic_beam_state st[2],
                                    int32_t* parent, int32_t* live_images, const double* sqrt_tab, float* top_val, int32_t* top_idx,
                                    int B, int K, int t0, int t1, int t_cap, int eos_id, int use_graph, void* stream) {
@@ -522,7 +522,8 @@ extern "C" int mic_lstm_beam_steps(const mic_lstm_decoder* dec, const mic_lstm_w
             MIC_TRY(mic_beam_select(cur, nxt, top_val, top_idx, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t, t_cap,
                                     eos_id, 1, stream));
             for (int l = 0; l < dec->layers; ++l) {
-                MIC_TRY(mic_gather_rows(wc->h[l], wn->h[l], parent, N, dec->Hd * 4, stream));
+                // the fp32 h of a layer is rewritten by the next step's cell before anything reads it: only the cell
+                // state and the GEMM input [x | h] travel with the survivors
                 MIC_TRY(mic_gather_rows(wc->c[l], wn->c[l], parent, N, dec->Hd * 4, stream));
                 MIC_TRY(mic_gather_rows(wc->xh[l], wn->xh[l], parent, N, dec->kpad[l] * sz, stream));
             }

@@ -497,7 +497,7 @@ int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, con
                   int pos, const void* feat_t, int ld_feat, void* stream);
 
 /* Steps [t0, t1) of LSTM beam search (models/image_captioner.py:118-159).  Step t runs on ws[t & 1]; the
- * survivors' h, c and [x | h] rows are gathered by parent into ws[(t + 1) & 1]; st as in mic_tr_beam_steps
+ * survivors' c and [x | h] rows are gathered by parent into ws[(t + 1) & 1]; st as in mic_tr_beam_steps
  * (anc unused), seq rows hold t_cap tokens.  top_val/top_idx: [B*K][K] scratch.  With use_graph the run is
  * captured once per argument set and replayed. */
 int mic_lstm_beam_steps(const mic_lstm_decoder* dec, const mic_lstm_workspace ws[2], const mic_beam_state st[2],
