@@ -4,6 +4,8 @@
 // 16-byte (or 4-float) vector along the hidden axis.
 #include "mic_common.h"
 
+#include <atomic>
+
 #include <stdlib.h>
 
 namespace {
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(256) void cross_fold_bias_kernel(const T* __restric
 template <typename T, int RG, int HEADS, bool MULTI> int launch_cross_fold_rg(const FoldArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)a.R * a.H + RG * HEADS * 64 + 8 * RG * (size_t)a.H + 2 * a.R);
     MIC_ARG_CHECK(lds <= 150 * 1024, "mic_cross_attn_folded: %zu bytes of LDS needed", lds);
-    static bool granted = false;
+    static std::atomic<bool> granted{false};  // lanes call from several host threads
     if (!granted) {
         MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_fold_kernel<T, RG, HEADS, MULTI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -913,7 +915,7 @@ template <typename T, int HEADS> int launch_cross_fold(const FoldArgs& a, hipStr
 
 template <typename T, int RG> int launch_cross_wide_rg(const AttnArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * (RG * (size_t)a.heads * 64 + 8 * RG * (size_t)a.H);
-    static bool granted = false;
+    static std::atomic<bool> granted{false};  // lanes call from several host threads
     if (!granted) {
         MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_wide_kernel<T, RG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -12,6 +12,8 @@
 // staging barrier and the two row reductions across waves.
 #include "mic_common.h"
 
+#include <atomic>
+
 #include <stdlib.h>
 
 namespace {
@@ -428,7 +430,7 @@ template <typename T, int MT, int NWV = 4> int launch_skinny(SkinnyArgs& a, hipS
     const size_t lds = (size_t)MT * 16 * ((size_t)a.K * sizeof(T) + 16);
     MIC_ARG_CHECK(lds <= 140 * 1024, "mic_linear_skinny: K=%d needs %zu bytes of LDS", a.K, lds);
     if (lds > 48 * 1024) {
-        static bool granted = false;
+        static std::atomic<bool> granted{false};  // lanes call from several host threads
         if (!granted) {
             MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<T, MT, NWV>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
@@ -456,7 +458,7 @@ template <typename T, int NW, int TPW> int launch_gl(const GemmLnArgs& a, hipStr
     const size_t lds = 16 * ((size_t)a.K * sizeof(T) + 16);
     MIC_ARG_CHECK(lds <= 150 * 1024, "mic_linear_res_ln: K=%d needs %zu bytes of LDS", a.K, lds);
     if (lds > 48 * 1024) {
-        static size_t granted = 0;  // raise the dynamic-LDS limit of this variant once per size class
+        static std::atomic<size_t> granted{0};  // raise the dynamic-LDS limit of this variant once per size class
         if (lds > granted) {
             MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_res_ln_kernel<T, NW, TPW>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

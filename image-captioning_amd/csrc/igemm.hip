@@ -13,6 +13,7 @@
 // before the MFMAs of tile k and written to the other LDS buffer after them; one barrier per tile.
 #include "mic_common.h"
 
+#include <atomic>
 #include <stdlib.h>
 
 #include <mutex>
@@ -470,7 +471,7 @@ struct ProfRec {
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};  // read outside the lock by every launch
 
 template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false>
 int launch(IgemmArgs& a, hipStream_t s, double flops) {
