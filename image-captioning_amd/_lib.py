@@ -105,7 +105,8 @@ class TrWorkspace(C.Structure):
 class LstmDecoder(C.Structure):
     _fields_ = [("dtype", i32), ("E", i32), ("Hd", i32), ("layers", i32), ("vocab", i32), ("kind", i32),
                 ("kpad", i32 * MAX_LAYERS), ("embed", vp), ("w", vp * MAX_LAYERS), ("b", vp * MAX_LAYERS),
-                ("ln_g", vp), ("ln_b", vp), ("out_w", vp), ("out_b", vp), ("out_k", i32)]
+                ("ln_g", vp), ("ln_b", vp), ("out_w", vp), ("out_b", vp), ("out_k", i32),
+                ("wf", vp * MAX_LAYERS), ("out_wf", vp)]
 
 
 class LstmWorkspace(C.Structure):

@@ -477,8 +477,7 @@ extern "C" int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspa
     }
     for (int l = 0; l < L; ++l) {
         const int in_dim = l == 0 ? E : Hd;
-        MIC_TRY(linear(dt, ws->xh[l], dec->kpad[l], N, dec->kpad[l], dec->w[l], dec->b[l], nullptr, 0, 0, ws->gates, MIC_F32, 4 * Hd,
-                       4 * Hd, 0, s));
+        MIC_TRY(proj(dt, dec->wf[l], ws->xh[l], dec->kpad[l], N, dec->kpad[l], dec->w[l], dec->b[l], ws->gates, MIC_F32, 4 * Hd, 4 * Hd, 0, s));
         void* up = nullptr;
         int ld_up = 0;
         if (l + 1 < L) { up = ws->xh[l + 1]; ld_up = dec->kpad[l + 1]; }
@@ -487,8 +486,7 @@ extern "C" int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspa
     }
     if (dec->kind == 1)
         MIC_TRY(mic_layernorm(ws->h[L - 1], dec->ln_g, dec->ln_b, ws->hn, ws->hnt, dec->out_k, dt, N, Hd, s));
-    return linear(dt, ws->hnt, dec->out_k, N, dec->out_k, dec->out_w, dec->out_b, nullptr, 0, 0, ws->logits, MIC_F32, dec->vocab,
-                  dec->vocab, 0, s);
+    return proj(dt, dec->out_wf, ws->hnt, dec->out_k, N, dec->out_k, dec->out_w, dec->out_b, ws->logits, MIC_F32, dec->vocab, dec->vocab, 0, s);
 }
 
 namespace {

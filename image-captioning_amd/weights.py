@@ -308,12 +308,15 @@ def build_lstm_decoder(sd: SD, kind: str, dtype: torch.dtype, device) -> tuple:
         kp = _round_up(wi.shape[1] + Hd, km)
         dec.kpad[l] = kp
         dec.w[l] = keep(matrix(torch.cat([wi, wh], dim=1), dtype, device, kp))
+        # fragment-ordered copy (rows padded to 128, K to kp) for the weight-streaming GEMM of the decode steps
+        dec.wf[l] = keep(frag_matrix(_pad_rows(torch.nn.functional.pad(torch.cat([wi, wh], dim=1).float(), (0, kp - wi.shape[1] - Hd))), dtype, device))
         dec.b[l] = keep(vector(sd[f"decoder.lstm.bias_ih_l{l}"] + sd[f"decoder.lstm.bias_hh_l{l}"], device))
     if kind == "intermediate":
         dec.ln_g = keep(vector(sd["decoder.layer_norm.weight"], device))
         dec.ln_b = keep(vector(sd["decoder.layer_norm.bias"], device))
     dec.out_k = _round_up(Hd, km)
     dec.out_w = keep(matrix(sd["decoder.linear.weight"], dtype, device, dec.out_k))
+    dec.out_wf = keep(frag_matrix(_pad_rows(torch.nn.functional.pad(sd["decoder.linear.weight"].float(), (0, dec.out_k - Hd))), dtype, device))
     dec.out_b = keep(vector(sd["decoder.linear.bias"], device))
     return dec, keep
 

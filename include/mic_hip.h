@@ -475,6 +475,10 @@ typedef struct mic_lstm_decoder {
     const void* out_w;                         /* dtype [vocab padded][Hd padded] */
     const float* out_b;
     int32_t out_k;                             /* padded K of the vocabulary GEMM */
+    /* optional: the same matrices in MFMA fragment order (mic_pack_weight_frag), rows zero-padded to 128; decode steps
+     * of at most 2048 rows then take the weight-streaming GEMM (mic_linear_skinny) instead of the tiled one */
+    const void* wf[MIC_MAX_LAYERS];
+    const void* out_wf;
 } mic_lstm_decoder;
 
 typedef struct mic_lstm_workspace {
