@@ -161,6 +161,7 @@ SIGNATURES = {
                                     C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_tr_sample_steps": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, vp]),
+    "mic_graph_cache_stats": (C.c_int, [P(i32), P(i32)]),
     "mic_lstm_step": (C.c_int, [P(LstmDecoder), P(LstmWorkspace), vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "mic_lstm_beam_steps": (C.c_int, [P(LstmDecoder), P(LstmWorkspace), P(BeamState), vp, vp, vp, vp, vp, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -14,19 +14,49 @@ namespace {
 // ---- HIP-graph cache for the launch-bound decode loops ---------------------------------------
 // A run of decode steps is ~40 dependent small kernels per step whose arguments depend only on the
 // driver's arguments, so the whole run is captured once per distinct argument set and replayed.
+//
+// The cache keeps the MIC_GRAPH_CACHE most recently used executables.  hipGraphLaunch is asynchronous
+// and lanes launch on different streams, so an executable that falls out of the cache may still be
+// running: it is parked with the event recorded after its last launch and destroyed only once that
+// event has completed.
+constexpr size_t MIC_GRAPH_CACHE = 32;
+struct GraphEntry {
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t done = nullptr;  // recorded after every launch, on the launch stream
+    uint64_t stamp = 0;         // value of GraphCache::clock at the last launch
+};
 struct GraphCache {
     std::mutex mu;
-    std::map<std::string, hipGraphExec_t> map;
-    std::vector<std::string> order;
+    std::map<std::string, GraphEntry> map;
+    std::vector<GraphEntry> retired;
+    uint64_t clock = 0;
 };
 GraphCache g_graphs;
 
+// under g_graphs.mu: free the parked executables whose last launch has finished
+void sweep_retired() {
+    auto& r = g_graphs.retired;
+    for (size_t i = 0; i < r.size();) {
+        if (hipEventQuery(r[i].done) == hipSuccess) {
+            (void)hipGraphExecDestroy(r[i].exec);
+            (void)hipEventDestroy(r[i].done);
+            r[i] = r.back();
+            r.pop_back();
+        } else {
+            ++i;
+        }
+    }
+    (void)hipGetLastError();  // hipErrorNotReady of a pending event is not an error of the caller
+}
+
 // body(stream) enqueues the work.  Capture runs on a stream the library owns (the caller's may be
 // the legacy default stream, which cannot be captured); the executable is launched on the caller's.
+// Capture and instantiation take milliseconds and run outside the lock, so other lanes keep launching.
 template <class Body> int run_graphed(const std::string& key, hipStream_t s, Body&& body) {
-    std::lock_guard<std::mutex> lk(g_graphs.mu);
+    std::unique_lock<std::mutex> lk(g_graphs.mu);
     auto it = g_graphs.map.find(key);
     if (it == g_graphs.map.end()) {
+        lk.unlock();
         hipGraph_t graph = nullptr;
         hipStream_t cap = nullptr;
         MIC_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
@@ -43,22 +73,36 @@ template <class Body> int run_graphed(const std::string& key, hipStream_t s, Bod
             return rc;
         }
         MIC_HIP_CHECK(e);
-        hipGraphExec_t exec = nullptr;
-        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        GraphEntry fresh;
+        const hipError_t ei = hipGraphInstantiate(&fresh.exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         MIC_HIP_CHECK(ei);
-        if (g_graphs.order.size() >= 32) {  // bounded: drop the oldest executable
-            auto old = g_graphs.map.find(g_graphs.order.front());
-            if (old != g_graphs.map.end()) {
-                (void)hipGraphExecDestroy(old->second);
+        e = hipEventCreateWithFlags(&fresh.done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipGraphExecDestroy(fresh.exec);
+            MIC_HIP_CHECK(e);
+        }
+        lk.lock();
+        it = g_graphs.map.find(key);
+        if (it != g_graphs.map.end()) {  // another lane captured the same key meanwhile: ours was never launched
+            (void)hipGraphExecDestroy(fresh.exec);
+            (void)hipEventDestroy(fresh.done);
+        } else {
+            sweep_retired();
+            while (g_graphs.map.size() >= MIC_GRAPH_CACHE) {  // park the least recently launched executable
+                auto old = g_graphs.map.begin();
+                for (auto j = g_graphs.map.begin(); j != g_graphs.map.end(); ++j)
+                    if (j->second.stamp < old->second.stamp) old = j;
+                g_graphs.retired.push_back(old->second);
                 g_graphs.map.erase(old);
             }
-            g_graphs.order.erase(g_graphs.order.begin());
+            it = g_graphs.map.emplace(key, fresh).first;
         }
-        it = g_graphs.map.emplace(key, exec).first;
-        g_graphs.order.push_back(key);
     }
-    MIC_HIP_CHECK(hipGraphLaunch(it->second, s));
+    // launch and event record stay under the lock: an entry is parked only together with the event of its last launch
+    it->second.stamp = ++g_graphs.clock;
+    MIC_HIP_CHECK(hipGraphLaunch(it->second.exec, s));
+    MIC_HIP_CHECK(hipEventRecord(it->second.done, s));
     return 0;
 }
 
@@ -122,6 +166,15 @@ ResnetPlan plan_resnet(const mic_resnet50* net, int B, int H, int W) {
 }
 
 }  // namespace
+
+extern "C" int mic_graph_cache_stats(int32_t* cached, int32_t* parked) {
+    MIC_ARG_CHECK(cached && parked, "mic_graph_cache_stats: null pointer");
+    std::lock_guard<std::mutex> lk(g_graphs.mu);
+    sweep_retired();
+    *cached = (int32_t)g_graphs.map.size();
+    *parked = (int32_t)g_graphs.retired.size();
+    return 0;
+}
 
 extern "C" int64_t mic_resnet50_workspace_bytes(const mic_resnet50* net, int B, int H, int W) {
     if (!net || B <= 0 || H < 32 || W < 32) return -1;

@@ -243,6 +243,10 @@ struct BeamArgs {
     int B, K, n_live_slots, t, t_cap, eos_id, in_place;
 };
 
+// A NaN key compares false against everything, which would give several candidates rank 0 and leave
+// other ranks without a winner; it sorts as -infinity instead (ties then fall back to candidate order).
+__device__ __forceinline__ double sane_key(double k) { return k == k ? k : -INFINITY; }
+
 __global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
     constexpr int CMAX = KMAX * KMAX + KMAX;
     __shared__ double c_key[CMAX], c_score[CMAX];
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
             }
         }
     }
+    if (lane < K) win[lane] = lane;  // every rank has a winner whatever the keys are
     __syncthreads();
     const int ncand = n_live * K + n_fin;
     // fill candidates: slot i contributes K entries (live) or itself (finished)
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
                 const int c = s_off[i];
                 const double sc = a.cur.score[g];
                 c_score[c] = sc;
-                c_key[c] = sc / a.sqrt_tab[a.cur.len[g]];
+                c_key[c] = sane_key(sc / a.sqrt_tab[a.cur.len[g]]);
                 c_slot[c] = i;
                 c_tok[c] = -1;
             }
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
             const int c = s_off[i] + j;
             const double sc = a.cur.score[g] + (double)a.top_val[(long long)g * K + j];
             c_score[c] = sc;
-            c_key[c] = sc / a.sqrt_tab[a.cur.len[g] + 1];
+            c_key[c] = sane_key(sc / a.sqrt_tab[a.cur.len[g] + 1]);
             c_slot[c] = i;
             c_tok[c] = a.top_idx[(long long)g * K + j];
         }

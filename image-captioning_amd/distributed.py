@@ -79,38 +79,66 @@ def gather_captions(tokens: torch.Tensor, lengths: torch.Tensor, scores: torch.T
     return buf[:, :T].contiguous(), buf[:, T].contiguous(), buf[:, T + 1].contiguous().view(torch.float32)
 
 
-def caption_dataset(model, caption, make_batch, n_total: int, n_tokens: int, batch: int = 256, lanes: int = 1):
+def _agree_ok(error: Optional[BaseException], device) -> None:
+    """Ranks agree on success before the one collective of the job: a rank that failed (or got the wrong width from
+    caption()) would otherwise leave while the others block in the gather.  One int all-reduce; every rank raises
+    when any rank failed."""
+    bad = 0 if error is None else 1
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        flag = torch.tensor([bad], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        bad_any = int(flag.item())
+    else:
+        bad_any = bad
+    if error is not None:
+        raise error
+    if bad_any:
+        raise RuntimeError("caption_dataset: another rank failed before the gather; this rank's shard is discarded")
+
+
+def caption_dataset(model, caption, make_batch, n_total: int, n_tokens: int, batch: int = 256, lanes=1):
     """Caption items 0..n_total-1 data-parallel: this rank takes its contiguous slice (shard_range), walks it in
     micro-batches of `batch`, and every rank returns the gathered (tokens int32 (n_total, n_tokens), lengths, scores)
     in item order.  `make_batch(lo, hi)` returns the input of items [lo, hi) on the model's device;
-    `caption(model, input)` returns (tokens (n, n_tokens) int32, lengths (n,), scores (n,)).  With lanes > 1 that
-    many micro-batches are in flight on the GPU at once (lanes.Lanes); the result does not depend on it.
-    No collective runs before the final gather."""
+    `caption(model, input)` returns (tokens (n, n_tokens) int32, lengths (n,), scores (n,)).  `lanes` is a number of
+    micro-batches to keep in flight on the GPU (a lanes.Lanes pool is created for the call) or an existing
+    lanes.Lanes pool, which keeps its streams, workspaces and captured graphs from call to call; the result does
+    not depend on it.  The only collectives are a one-int agreement that every rank got through its shard and
+    the final gather; when any rank failed, every rank raises instead of entering the gather."""
     if n_total < 0 or batch < 1 or n_tokens < 1:
         raise ValueError(f"bad sizes n_total={n_total} batch={batch} n_tokens={n_tokens}")
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     lo, hi = shard_range(n_total, rank, world)
     spans = [(a, min(hi, a + batch)) for a in range(lo, hi, batch)]
+    dev = getattr(model, "device", None) or "cpu"
 
     def work(m, span):
         tokens, lengths, scores = caption(m, make_batch(*span))
         return tokens.clone(), lengths.clone(), scores.clone()  # a model may hand out views of buffers it reuses
 
-    if lanes > 1 and len(spans) > 1:
-        from .lanes import Lanes
-        parts = Lanes(model, lanes).map(work, spans)
-    else:
-        parts = [work(model, s) for s in spans]
-    if parts:
-        tokens = torch.cat([p[0] for p in parts]).to(torch.int32)
-        lengths = torch.cat([p[1] for p in parts]).to(torch.int32)
-        scores = torch.cat([p[2] for p in parts]).to(torch.float32)
-    else:  # more ranks than micro-batches: an empty shard still takes part in the gather
-        dev = getattr(model, "device", None) or "cpu"
-        tokens = torch.empty(0, n_tokens, dtype=torch.int32, device=dev)
-        lengths = torch.empty(0, dtype=torch.int32, device=dev)
-        scores = torch.empty(0, dtype=torch.float32, device=dev)
-    if tokens.shape[1] != n_tokens:
-        raise ValueError(f"caption() returned {tokens.shape[1]} tokens per item, expected {n_tokens}")
+    error: Optional[BaseException] = None
+    tokens = lengths = scores = None
+    try:
+        pool = None if isinstance(lanes, int) else lanes
+        if pool is None and lanes > 1 and len(spans) > 1:
+            from .lanes import Lanes
+            pool = Lanes(model, lanes)
+        if pool is not None and len(pool) > 1 and len(spans) > 1:
+            parts = pool.map(work, spans)
+        else:
+            parts = [work(model, s) for s in spans]
+        if parts:
+            tokens = torch.cat([p[0] for p in parts]).to(torch.int32)
+            lengths = torch.cat([p[1] for p in parts]).to(torch.int32)
+            scores = torch.cat([p[2] for p in parts]).to(torch.float32)
+            if tokens.shape[1] != n_tokens:
+                raise ValueError(f"caption() returned {tokens.shape[1]} tokens per item, expected {n_tokens}")
+        else:  # more ranks than micro-batches: an empty shard still takes part in the gather
+            tokens = torch.empty(0, n_tokens, dtype=torch.int32, device=dev)
+            lengths = torch.empty(0, dtype=torch.int32, device=dev)
+            scores = torch.empty(0, dtype=torch.float32, device=dev)
+    except Exception as e:  # noqa: BLE001 - re-raised on every rank after the agreement
+        error = e
+    _agree_ok(error, dev)
     return gather_captions(tokens, lengths, scores, n_total)

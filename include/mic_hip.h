@@ -453,8 +453,8 @@ int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int
  * live_images: int32[t_cap] device counters, entry t receives the number of images with a live beam
  * after step t.  models/transformer.py:589-632.
  * use_graph != 0: the run is captured into a HIP graph the first time a given argument set is seen
- * (every pointer and size is part of the key) and replayed afterwards; the library keeps at most 32
- * executables.  Capture instantiates a graph, i.e. allocates inside the runtime, on that first call. */
+ * (every pointer and size is part of the key) and replayed afterwards; the library keeps the 32 most
+ * recently launched executables and frees a dropped one once its last launch has finished.  Capture instantiates a graph, i.e. allocates inside the runtime, on that first call. */
 int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const mic_beam_state st[2],
                       int32_t* parent, int32_t* live_images, const double* sqrt_tab, int B, int K,
                       int t0, int t1, int eos_id, int want_attn, int use_graph, void* stream);
@@ -464,6 +464,10 @@ int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, con
 int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_workspace* ws, int32_t* tokens,
                         uint8_t* finished, float* total, int32_t* live_rows, float inv_temp, const float* u,
                         int t0, int t1, int pad_id, int eos_id, int want_attn, int use_graph, void* stream);
+
+/* Executables the graph cache of the *_steps drivers holds (at most 32, least recently launched dropped first) and
+ * dropped ones still parked because their last launch has not finished.  Diagnostic; no reference counterpart. */
+int mic_graph_cache_stats(int32_t* cached, int32_t* parked);
 
 typedef struct mic_lstm_decoder {
     int32_t dtype, E, Hd, layers, vocab, kind; /* kind 0 = basic, 1 = intermediate */

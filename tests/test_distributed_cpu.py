@@ -44,6 +44,19 @@ def _worker(rank, world, port, n_total, q):
     assert all(torch.equal(x, y) for x, y in zip(job, out_all))
     tiny = D.caption_dataset(Host(), caption, lambda a, b: torch.arange(a, b), 1, T, batch=3)
     assert tiny[0].tolist() == [[t for t in range(T)]] and tiny[1].tolist() == [1]
+    # a rank that fails inside its shard must not leave the others blocked in the gather: every rank raises
+    def broken(_model, ix):
+        if rank == 1:
+            raise ValueError("rank 1 cannot caption")
+        return caption(_model, ix)
+
+    try:
+        D.caption_dataset(Host(), broken, lambda a, b: torch.arange(a, b), n_total, T, batch=3)
+        raise AssertionError("caption_dataset returned although rank 1 failed")
+    except ValueError as e:
+        assert rank == 1 and "cannot caption" in str(e)
+    except RuntimeError as e:
+        assert rank == 0 and "another rank failed" in str(e)
     q.put((rank, [t.tolist() for t in out_all], None if out_dst[0] is None else [t.tolist() for t in out_dst]))
     dist.barrier()
     dist.destroy_process_group()
