@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ("stride", i32), ("pad_h", i32), ("pad_w", i32),
                 ("ldc", i32), ("ld_res", i32), ("relu", i32), ("k_valid", i32),
                 ("in2", vp), ("in2_img_stride", i64), ("in2_row_stride", i64),
-                ("in2_pix_stride", i32), ("stride2", i32), ("K2", i32)]
+                ("in2_pix_stride", i32), ("stride2", i32), ("K2", i32), ("w_rows", i32)]
 
 
 class LnRef(C.Structure):
@@ -120,6 +120,7 @@ SIGNATURES = {
     "mic_last_error": (C.c_char_p, []),
     "mic_version": (C.c_int, []),
     "mic_conv2d": (C.c_int, [P(ConvDesc), vp]),
+    "mic_conv2d_variant": (C.c_int, [P(ConvDesc), C.c_int, vp]),
     "mic_profile_begin": (C.c_int, [C.c_int]),
     "mic_profile_end": (C.c_int, [P(i32), P(C.c_double), P(C.c_double)]),
     "mic_pack_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -499,11 +499,12 @@ int launch(IgemmArgs& a, hipStream_t s, double flops) {
 
 // Tile variants: (BM, BN, KT).  The heuristic below picks one from the problem shape; the
 // environment variable MIC_IGEMM_FORCE=<index> pins one for tuning runs.
-template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
-    static const int forced = [] {
+template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, int variant) {
+    static const int env_forced = [] {
         const char* e = getenv("MIC_IGEMM_FORCE");
         return e ? atoi(e) : -1;
     }();
+    const int forced = variant >= 0 ? variant : env_forced;
     int v = forced;
     if (v < 0) {
         // measured on MI355X over the ResNet-50 (batch 256) and decode-step shapes: shallow stages win
@@ -593,7 +594,8 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops) {
 
 }  // namespace
 
-extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
+namespace {
+int conv2d_impl(const mic_conv_desc* d, void* stream, int variant) {
     MIC_ARG_CHECK(d && d->in && d->w && d->out, "mic_conv2d: null pointer");
     MIC_ARG_CHECK(d->dtype == MIC_F32 || d->dtype == MIC_BF16, "mic_conv2d: bad dtype %d", d->dtype);
     MIC_ARG_CHECK(d->out_dtype == MIC_F32 || d->out_dtype == MIC_BF16, "mic_conv2d: bad out_dtype %d", d->out_dtype);
@@ -606,6 +608,9 @@ extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
                   "mic_conv2d: K=%d is not taps*run (run=%d, kw_taps=%d)", d->K, d->run, d->kw_taps);
     MIC_ARG_CHECK(d->OH > 0 && d->OW > 0 && d->M % (d->OH * d->OW) == 0, "mic_conv2d: M=%d not a multiple of OH*OW", d->M);
     MIC_ARG_CHECK(d->stride > 0 && d->IH > 0 && d->IW > 0 && d->ldc >= d->N, "mic_conv2d: bad geometry");
+    // every tile loads whole 128-row groups of the weight matrix without a per-row guard
+    MIC_ARG_CHECK(d->w_rows == 0 || d->w_rows >= (d->N + 127) / 128 * 128,
+                  "mic_conv2d: weight matrix has %d rows, N=%d needs it zero-padded to %d", d->w_rows, d->N, (d->N + 127) / 128 * 128);
     const int vec = 16 / (int)mic_dtype_size(d->dtype);
     MIC_ARG_CHECK(d->in_pix_stride % 4 == 0 && d->in_row_stride % vec == 0 && d->in_img_stride % vec == 0 &&
                       ((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0,
@@ -634,7 +639,15 @@ extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) {
                (!d->res || (d->ld_res % 8 == 0 && ((uintptr_t)d->res) % 16 == 0));
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * d->N * ((d->k_valid > 0 ? d->k_valid : d->K) + a.K2);
-    return d->dtype == MIC_BF16 ? dispatch<bf16_t>(a, s, flops) : dispatch<float>(a, s, flops);
+    return d->dtype == MIC_BF16 ? dispatch<bf16_t>(a, s, flops, variant) : dispatch<float>(a, s, flops, variant);
+}
+}  // namespace
+
+extern "C" int mic_conv2d(const mic_conv_desc* d, void* stream) { return conv2d_impl(d, stream, -1); }
+
+extern "C" int mic_conv2d_variant(const mic_conv_desc* d, int variant, void* stream) {
+    MIC_ARG_CHECK(variant >= 0 && variant <= 17, "mic_conv2d_variant: tile variant %d outside [0,17]", variant);
+    return conv2d_impl(d, stream, variant);
 }
 
 extern "C" int mic_profile_begin(int max_launches) {

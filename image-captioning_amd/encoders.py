@@ -75,7 +75,7 @@ class ResNet50Encoder:
         d.OH = d.OW = d.IH = d.IW = 1
         d.in_img_stride, d.in_row_stride, d.in_pix_stride = 2048, 0, 4
         d.kw_taps, d.run, d.stride = 1, 2048, 1
-        d.ldc, d.relu = self.out_dim, int(relu)
+        d.ldc, d.relu, d.w_rows = self.out_dim, int(relu), self.head_w.shape[0]
         L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()), "mic_conv2d(encoder head)")
         return out
 
@@ -143,6 +143,6 @@ class SwinV2Encoder:
         d.OH = d.OW = d.IH = d.IW = 1
         d.in_img_stride, d.in_row_stride, d.in_pix_stride = K, 0, 4
         d.kw_taps, d.run, d.stride = 1, K, 1
-        d.ldc, d.relu = self.out_dim, 1
+        d.ldc, d.relu, d.w_rows = self.out_dim, 1, self.head_w.shape[0]
         L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()), "mic_conv2d(swin projection)")  # models/encoders/swin.py:70
         return out.view(B, S, self.out_dim)

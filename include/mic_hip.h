@@ -83,8 +83,15 @@ typedef struct mic_conv_desc {
     const void* in2;
     int64_t in2_img_stride, in2_row_stride;
     int32_t in2_pix_stride, stride2, K2;
+    int32_t w_rows;       /* rows the weight matrix really has (0 = not stated): when stated, a matrix shorter than
+                             ceil(N/128)*128 rows is rejected instead of being read past its end */
 } mic_conv_desc;
 int mic_conv2d(const mic_conv_desc* d, void* stream);
+/* The same layer on a named tile variant instead of the one the shape heuristic picks (0: 128x128, 1: 128x128 with
+ * 128-byte stages, 4: 64x64, 8: 128x64, 11: 128x256, 16: 256x256 filled directly into LDS, ...; the list is in
+ * csrc/igemm.hip).  Every variant computes the same result for every shape; this entry exists for tuning sweeps and
+ * for per-variant parity tests.  No reference counterpart. */
+int mic_conv2d_variant(const mic_conv_desc* d, int variant, void* stream);
 
 /* Per-launch timing of the GEMM/conv kernel for roofline reports.  Between begin and end every
  * mic_conv2d launch is bracketed by two hipEvents on its stream (no synchronisation).  end waits for
