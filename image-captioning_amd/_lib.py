@@ -10,6 +10,7 @@ import os
 
 F32, BF16 = 0, 1
 MAX_BEAM, MAX_LAYERS = 8, 8
+STATIC_SCRATCH_BYTES = 8 << 20  # MIC_STATIC_SCRATCH_BYTES
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmic_hip.so")
@@ -158,6 +159,7 @@ SIGNATURES = {
     "mic_resnet50_forward": (C.c_int, [P(Resnet50), vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]),
     "mic_tr_cross_kv": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, vp]),
     "mic_tr_step": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "mic_tr_step_static": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mic_tr_beam_steps": (C.c_int, [P(TrDecoder), P(TrWorkspace), P(BeamState), vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_tr_sample_steps": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int,

@@ -455,6 +455,23 @@ int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const
 int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
                 const int32_t* anc, int t, int attn_mode, void* stream);
 
+/* mic_tr_step for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same step, same kernels,
+ * same results as mic_tr_step; the difference is where the step's temporaries live: the fields x, xt, y, qkv,
+ * o, ffh and stats[0..1] of `io` are IGNORED (may be NULL) and replaced by slices of a device array of
+ * MIC_STATIC_SCRATCH_BYTES that is part of the library's code object (each GPU the library runs on holds its
+ * own copy until the process ends).  Every other field of `io` (sizes, logits, caches, cross keys/values,
+ * attn) is the caller's memory as in mic_tr_step.  The call allocates nothing; the first call on a device
+ * looks the array's address up.  The temporaries take, each rounded up to 256 bytes,
+ *     N*H*(4 + e + 4 + 12 + e + 2e) + 2 * N*ceil(H/128)*8 bytes   (e = element size of dec->dtype),
+ * and a call that needs more than MIC_STATIC_SCRATCH_BYTES is rejected with MIC_ERR_ARG (512 rows of hidden
+ * size 512 in bf16 fit).  All calls on one GPU share that GPU's array, whatever their stream: calls that
+ * overlap in time on one GPU race.  Nothing in the array has to start at zero (each temporary is written by the
+ * step before it is read), so consecutive calls of any sizes need no clearing in between. */
+#define MIC_STATIC_SCRATCH_BYTES (8u << 20)
+int mic_tr_step_static(const mic_tr_decoder* dec, const mic_tr_workspace* io, const int32_t* tokens, int ld_tok,
+                       const int32_t* anc, int t, int attn_mode, void* stream);
+
 /* Steps [t0, t1) of transformer beam search on device: mic_tr_step, log-softmax top-K, beam
  * selection, ping-ponging between st[0] and st[1] (st[t & 1] is current at step t).
  * live_images: int32[t_cap] device counters, entry t receives the number of images with a live beam
