@@ -31,6 +31,12 @@ class ConvDesc(C.Structure):
                 ("in2_pix_stride", i32), ("stride2", i32), ("K2", i32), ("w_rows", i32)]
 
 
+class FusedBlockDesc(C.Structure):
+    _fields_ = [("t1", vp), ("w2", vp), ("b2", vp), ("w3", vp), ("b3", vp), ("res", vp), ("xout", vp), ("w1n", vp), ("b1n", vp),
+                ("t1n", vp), ("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("C2", i32),
+                ("w2_rows", i32), ("w3_rows", i32), ("w1n_rows", i32)]
+
+
 class LnRef(C.Structure):
     _fields_ = [("raw", vp), ("stats", vp), ("gamma", vp), ("beta", vp), ("ld", i32), ("parts", i32), ("width", i32)]
 
@@ -122,6 +128,8 @@ SIGNATURES = {
     "mic_version": (C.c_int, []),
     "mic_conv2d": (C.c_int, [P(ConvDesc), vp]),
     "mic_conv2d_variant": (C.c_int, [P(ConvDesc), C.c_int, vp]),
+    "mic_bottleneck_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mic_bottleneck_fused": (C.c_int, [P(FusedBlockDesc), vp]),
     "mic_profile_begin": (C.c_int, [C.c_int]),
     "mic_profile_end": (C.c_int, [P(i32), P(C.c_double), P(C.c_double)]),
     "mic_pack_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -195,8 +195,8 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
     void* pack = base;
     void* X[2] = {base + p.pack, base + p.pack + p.big};
     void* DS = base + p.pack + 2 * p.big;
-    void* T1 = base + p.pack + 3 * p.big;
-    void* T2 = base + p.pack + 3 * p.big + p.mid;
+    void* T1 = base + p.pack + 3 * p.big;             // first-convolution output of the running block
+    void* T2 = base + p.pack + 3 * p.big + p.mid;     // 3x3 output, or the next block's first-convolution output
 
     // stem: image -> zero-bordered 4-channel pixels; each of the 7 kernel rows is one run of
     // 8 pixels x 4 channels = 32 contiguous elements (the 8th pixel and 4th channel meet zero weights)
@@ -219,11 +219,42 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
     int nblocks = 0;
     for (int st = 0; st < 4; ++st) nblocks += net->blocks_per_stage[st];
     MIC_ARG_CHECK(nblocks > 0 && nblocks <= 16, "mic_resnet50_forward: %d bottlenecks (max 16)", nblocks);
+    // Identity blocks of the stages whose layers are bound by HBM traffic run as one launch per block: 3x3 convolution,
+    // expansion + residual + ReLU and the NEXT block's first 1x1 convolution (mic_bottleneck_fused).  `have_t1` says that
+    // T1 already holds the first convolution of the block about to run (written by the previous block's launch).
+    static const bool no_fusion = getenv("MIC_NO_BLOCK_FUSION") != nullptr;
+    bool have_t1 = false;
     for (int st = 0; st < 4; ++st) {
         for (int k = 0; k < net->blocks_per_stage[st]; ++k, ++bi) {
             const mic_conv_layer* L = net->conv[bi];
-            int h1, w1, h2, w2, h3, w3;
-            MIC_TRY(conv_layer(dt, L[0], X[cur], B, h, w, nullptr, T1, &h1, &w1, s));
+            int h1 = h, w1 = w, h2, w2, h3, w3;
+            const bool identity = L[3].cout == 0 && L[1].stride == 1 && L[1].kh == 3 && L[1].kw == 3 && L[1].pad == 1 && L[0].stride == 1 &&
+                                  L[0].kh == 1 && L[2].kh == 1 && L[2].stride == 1 && L[1].cin == L[1].cout && L[2].cin == L[1].cout &&
+                                  L[2].cout == 4 * L[1].cout && L[0].cout == L[1].cin && L[0].relu && L[1].relu && L[2].relu;
+            if (!no_fusion && identity && mic_bottleneck_fused_supported(dt, L[1].cout, 0)) {
+                const int C = L[1].cout;
+                if (!have_t1) MIC_TRY(conv_layer(dt, L[0], X[cur], B, h, w, nullptr, T1, &h1, &w1, s));
+                // the next block's first convolution rides along when it is a plain 1x1 over this block's output
+                const mic_conv_layer* nx = bi + 1 < nblocks ? &net->conv[bi + 1][0] : nullptr;
+                int C2 = 0;
+                if (nx && nx->w && nx->kh == 1 && nx->kw == 1 && nx->stride == 1 && nx->pad == 0 && nx->cin == 4 * C && nx->relu &&
+                    mic_bottleneck_fused_supported(dt, C, nx->cout))
+                    C2 = nx->cout;
+                void* dst = (bi == nblocks - 1) ? out : X[cur ^ 1];
+                mic_fused_block_desc d{};
+                d.t1 = T1; d.w2 = L[1].w; d.b2 = L[1].bias; d.w3 = L[2].w; d.b3 = L[2].bias; d.res = X[cur]; d.xout = dst;
+                d.dtype = dt; d.B = B; d.H = h; d.W = w; d.C = C; d.C2 = C2;
+                // the host pads every weight matrix to a multiple of 128 rows (mic_conv_layer contract)
+                d.w2_rows = (C + 127) / 128 * 128; d.w3_rows = (4 * C + 127) / 128 * 128;
+                if (C2) { d.w1n = nx->w; d.b1n = nx->bias; d.t1n = T2; d.w1n_rows = (C2 + 127) / 128 * 128; }
+                MIC_TRY(mic_bottleneck_fused(&d, s));
+                if (C2) { void* t = T1; T1 = T2; T2 = t; }
+                have_t1 = C2 != 0;
+                cur ^= 1;
+                continue;
+            }
+            if (!have_t1) MIC_TRY(conv_layer(dt, L[0], X[cur], B, h, w, nullptr, T1, &h1, &w1, s));
+            have_t1 = false;
             MIC_TRY(conv_layer(dt, L[1], T1, B, h1, w1, nullptr, T2, &h2, &w2, s));
             const void* idt = X[cur];
             void* dst = (bi == nblocks - 1) ? out : X[cur ^ 1];

@@ -1,0 +1,397 @@
+// Fused tail of a ResNet bottleneck and head of the next one, bf16, for the identity blocks of the
+// early stages where the layer-by-layer trunk is bound by HBM traffic:
+//
+//   t2  = relu(conv3x3(t1) * W2 + b2)                 [128 pixels x C]     stays in LDS
+//   x'  = relu(t2 * W3^T + b3 + x)                    [128 pixels x 4C]    written once (needed as the next residual)
+//   t1' = relu(x' * W1n^T + b1n)                      [128 pixels x C2]    written once (input of the next 3x3)
+//
+// Layer by layer the 4C-wide tensor x' is written by conv3 and read again by the next conv1, and t2 makes a
+// round trip of its own; here one workgroup keeps a tile of 128 output pixels on chip from the 3x3
+// convolution to the next block's 1x1, so per block the HBM traffic is t1 + x in, x' + t1' out.
+//
+// One workgroup = 256 threads = 2x2 waves, 128 output pixels.
+//   phase 1: implicit-GEMM 3x3 (stride 1, pad 1), K = 9C in 64-byte k-tiles, register-staged double buffer;
+//   phase 2, per chunk of 64 output channels of the 4C: GEMM over K = C from the LDS image of t2 and a staged
+//            slice of W3; the epilogue adds bias and the residual slice (staged coalesced into the tile's LDS
+//            image beforehand), applies the ReLU, leaves the bf16 tile in LDS and copies it out in full rows;
+//   phase 3, same chunk: the tile just produced is 64 of the 4C input channels of the next conv1; its GEMM
+//            accumulates over the chunks.
+// The weight and residual slices of chunk n+1 are requested into registers while chunk n computes.
+// Every LDS operand image is [k-tile][row][64 bytes] with the 16-byte chunks XOR-swizzled as in igemm.hip, so
+// a wave's fragment read (ds_read_b128) touches 16 distinct 16-byte slots per lane group.
+#include "mic_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+struct FusedArgs {
+    const bf16_t* t1;    // [B][IH][IW][C]
+    const bf16_t* w2;    // [C padded to 128][9C], k = (kh*3 + kw)*C + c
+    const float* b2;     // [C]
+    const bf16_t* w3;    // [4C][C]
+    const float* b3;     // [4C]
+    const bf16_t* res;   // [M][4C]
+    bf16_t* xout;        // [M][4C]
+    const bf16_t* w1n;   // [C2 padded to 128][4C] or nullptr
+    const float* b1n;    // [C2]
+    bf16_t* t1n;         // [M][C2]
+    int M, IH, IW, tiles;
+    int dbg;  // timing experiments only (MIC_FUSED_DEBUG): bit 0 skips phase 1, 1 phase 2, 2 its epilogue, 3 the copy-out, 4 phase 3
+};
+
+__device__ __forceinline__ int lds_off(int row, int q) { return row * 64 + ((q ^ (((row >> 3) & 1) << 1)) << 4); }
+
+typedef unsigned int u32x4_fwd __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mma(const u32x4_fwd& wf, const u32x4_fwd& xf, f32x4_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, xf), acc, 0, 0, 0);
+}
+
+// native vector type for 16-byte moves: aggregate copies of HIP's uint4 struct between address spaces are emitted as
+// memcpy through a private stack slot, which puts the register prefetch in scratch memory
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct alignas(8) B4 {
+    bf16_t v[4];
+};
+
+// C: channels of the 3x3 convolution (64 or 128); C2: output channels of the next block's first convolution
+// fused behind it (0: none).
+template <int C, int C2>
+__global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) {
+    constexpr int BM = 128, NB = 64, NOUT = 4 * C, NCH = NOUT / NB;
+    constexpr int KT1 = 9 * C / 32;          // k-tiles of phase 1
+    constexpr int KT2 = C / 32;              // k-tiles of phase 2
+    constexpr int TN1 = C / 32;              // 16-channel tiles per wave, phase 1 (wave owns C/2 channels)
+    constexpr int TN3 = C2 > 0 ? C2 / 32 : 1;
+    constexpr int WC1 = C / 64;              // staged weight rows per thread per k-tile, phase 1
+    // LDS regions (bytes)
+    constexpr int STAGE = (BM + C) * 64;                 // one phase-1 stage: 128 pixel rows then C weight rows
+    constexpr int WA = KT2 * NB * 64;                    // W3 slice  [KT2][64 rows][64 B]
+    constexpr int WB = C2 > 0 ? 2 * C2 * 64 : 0;         // W1n slice [2][C2 rows][64 B]
+    constexpr int A3 = 2 * BM * 64;                      // chunk tile [2][128 rows][64 B]
+    constexpr int P23 = WA + WB + A3;
+    constexpr int OUT3 = C2 > 0 ? (C2 / 32) * BM * 64 : 0;  // t1' tile [C2/32][128 rows][64 B], over the phase-2/3 region
+    constexpr int R0 = (2 * STAGE > P23 ? 2 * STAGE : P23) > OUT3 ? (2 * STAGE > P23 ? 2 * STAGE : P23) : OUT3;
+    constexpr int A2 = KT2 * BM * 64;                    // t2 tile [KT2][128 rows][64 B]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R0 + A2];
+    unsigned char* const sA2 = smem + R0;
+    unsigned char* const sWa = smem;
+    unsigned char* const sWb = smem + WA;
+    unsigned char* const sA3 = smem + WA + WB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // blocks b and b+8 share an XCD: give each XCD a contiguous range of tiles (neighbouring tiles share halo rows)
+    int tile;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int m0 = tile * BM;
+    const int HW = a.IH * a.IW;
+
+    // ---------------- phase 1: 3x3 convolution ----------------
+    f32x4_t acc1[TN1][4];
+#pragma unroll
+    for (int j = 0; j < TN1; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc1[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {
+        const int q_own = tid & 3, row0 = tid >> 2;  // 64 rows per pass of the workgroup's threads
+        long long x_img[2];
+        int x_h[2], x_w[2];
+        bool x_ok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + row0 + i * 64;
+            x_ok[i] = m < a.M;
+            m = x_ok[i] ? m : a.M - 1;
+            const int b = m / HW, r = m - b * HW, oh = r / a.IW, ow = r - oh * a.IW;
+            x_img[i] = (long long)b * HW * C + q_own * 8;
+            x_h[i] = oh - 1;
+            x_w[i] = ow - 1;
+        }
+        const bf16_t* w_src = a.w2 + (long long)row0 * (9 * C) + q_own * 8;
+        int kh = 0, kw = 0, c0 = 0;
+        u32x4 xr[2], wr[WC1];
+        auto load_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // unconditional load from a clamped (always valid) pixel, zeroed afterwards when the tap falls into the
+                // padding or the row is past M: a load under a condition would be branched around and waited for at once
+                const int ih = x_h[i] + kh, iw = x_w[i] + kw;
+                const bool ok = x_ok[i] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+                const int ihc = min(max(ih, 0), a.IH - 1), iwc = min(max(iw, 0), a.IW - 1);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(a.t1 + x_img[i] + ((long long)ihc * a.IW + iwc) * C + c0);
+                xr[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int i = 0; i < WC1; ++i) wr[i] = *reinterpret_cast<const u32x4*>(w_src + (long long)i * 64 * (9 * C));
+            w_src += 32;
+            c0 += 32;
+            if (c0 == C) {
+                c0 = 0;
+                if (++kw == 3) { kw = 0; ++kh; }
+            }
+        };
+        auto store_stage = [&](int buf) __attribute__((always_inline)) {
+            unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + lds_off(row0 + i * 64, q_own)) = xr[i];
+#pragma unroll
+            for (int i = 0; i < WC1; ++i) *reinterpret_cast<u32x4*>(base + BM * 64 + lds_off(row0 + i * 64, q_own)) = wr[i];
+        };
+        int xf_off[4], wf_off[TN1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf_off[i] = lds_off(wm * 64 + i * 16 + fr, fq);
+#pragma unroll
+        for (int j = 0; j < TN1; ++j) wf_off[j] = BM * 64 + lds_off(wn * (C / 2) + j * 16 + fr, fq);
+        load_stage();
+        store_stage(0);
+        __syncthreads();
+        int cur = 0;
+        for (int st = 0; st < ((a.dbg & 1) ? 1 : KT1); ++st) {
+            const bool more = st + 1 < KT1;
+            if (more) load_stage();
+            const unsigned char* base = smem + cur * STAGE;
+            u32x4 xf[4], wf[TN1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4*>(base + xf_off[i]);
+#pragma unroll
+            for (int j = 0; j < TN1; ++j) wf[j] = *reinterpret_cast<const u32x4*>(base + wf_off[j]);
+#pragma unroll
+            for (int j = 0; j < TN1; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mma(wf[j], xf[i], acc1[j][i]);
+            if (more) store_stage(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---------------- slices of chunk `nc`: W3 rows, W1n columns, residual ----------------
+    constexpr int NWA = WA / 16 / 256;                    // 16-byte pieces per thread
+    constexpr int NWB = C2 > 0 ? WB / 16 / 256 : 1;
+    u32x4 pwa[NWA], pwb[NWB], pres[4];
+    auto prefetch = [&](int nc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWA; ++i) {  // the slice is 64 whole rows of W3: one contiguous block
+            const int c = tid + 256 * i;
+            pwa[i] = *reinterpret_cast<const u32x4*>(a.w3 + (long long)nc * NB * C + c * 8);
+        }
+        if constexpr (C2 > 0) {
+#pragma unroll
+            for (int i = 0; i < NWB; ++i) {  // 64 columns (128 bytes) of every row of W1n
+                const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+                pwb[i] = *reinterpret_cast<const u32x4*>(a.w1n + (long long)row * NOUT + nc * NB + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            const int m = min(m0 + row, a.M - 1);  // rows past M read the last row; their results are never stored
+            pres[i] = *reinterpret_cast<const u32x4*>(a.res + (long long)m * NOUT + nc * NB + ch * 8);
+        }
+    };
+    auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWA; ++i) {
+            const int c = tid + 256 * i, row = c / (C / 8), ch = c % (C / 8);
+            *reinterpret_cast<u32x4*>(sWa + (ch >> 2) * NB * 64 + lds_off(row, ch & 3)) = pwa[i];
+        }
+        if constexpr (C2 > 0) {
+#pragma unroll
+            for (int i = 0; i < NWB; ++i) {
+                const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+                *reinterpret_cast<u32x4*>(sWb + (ch >> 2) * C2 * 64 + lds_off(row, ch & 3)) = pwb[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            *reinterpret_cast<u32x4*>(sA3 + (ch >> 2) * BM * 64 + lds_off(row, ch & 3)) = pres[i];
+        }
+    };
+    prefetch(0);
+
+    // ---------------- t2 = relu(acc1 + b2) -> LDS ----------------
+#pragma unroll
+    for (int j = 0; j < TN1; ++j) {
+        const int ch0 = wn * (C / 2) + j * 16 + fq * 4;  // this lane's 4 consecutive channels
+        const float4 b = *reinterpret_cast<const float4*>(a.b2 + ch0);
+        const int kt = ch0 >> 5, o = ch0 & 31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + fr;
+            B4 p;
+            p.v[0] = (bf16_t)fmaxf(acc1[j][i][0] + b.x, 0.f);
+            p.v[1] = (bf16_t)fmaxf(acc1[j][i][1] + b.y, 0.f);
+            p.v[2] = (bf16_t)fmaxf(acc1[j][i][2] + b.z, 0.f);
+            p.v[3] = (bf16_t)fmaxf(acc1[j][i][3] + b.w, 0.f);
+            *reinterpret_cast<B4*>(sA2 + kt * BM * 64 + lds_off(row, o >> 3) + (o & 7) * 2) = p;
+        }
+    }
+
+    // ---------------- phases 2 and 3 over the chunks of 64 output channels ----------------
+    f32x4_t acc3[TN3][4];
+#pragma unroll
+    for (int j = 0; j < TN3; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc3[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int x2_off[4], x3_off[4], wa_off[2], wb_off[TN3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x2_off[i] = lds_off(wm * 64 + i * 16 + fr, fq);
+        x3_off[i] = lds_off(wm * 64 + i * 16 + fr, fq);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wa_off[j] = lds_off(wn * 32 + j * 16 + fr, fq);
+#pragma unroll
+    for (int j = 0; j < TN3; ++j) wb_off[j] = lds_off(wn * (C2 > 0 ? C2 / 2 : 0) + j * 16 + fr, fq);
+
+#pragma unroll
+    for (int nc = 0; nc < NCH; ++nc) {
+        __syncthreads();  // the previous chunk's readers of Wa / Wb / the tile (and phase 1's of its stages) are done
+        stash();
+        if (nc + 1 < NCH) prefetch(nc + 1);
+        __syncthreads();
+        f32x4_t acc2[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc2[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!(a.dbg & 2))
+#pragma unroll
+        for (int kt = 0; kt < KT2; ++kt) {
+            u32x4 xf[4], wf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sA2 + kt * BM * 64 + x2_off[i]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const u32x4*>(sWa + kt * NB * 64 + wa_off[j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mma(wf[j], xf[i], acc2[j][i]);
+        }
+        // epilogue in place: the tile image already holds the residual slice
+        if (!(a.dbg & 4))
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = j * 16 + fq * 4;  // channel within this wave's 32 = k within k-tile `wn` of the chunk
+            const float4 b = *reinterpret_cast<const float4*>(a.b3 + nc * NB + wn * 32 + o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + fr;
+                B4* cell = reinterpret_cast<B4*>(sA3 + wn * BM * 64 + lds_off(row, o >> 3) + (o & 7) * 2);
+                const B4 r = *cell;
+                B4 p;
+                p.v[0] = (bf16_t)fmaxf(acc2[j][i][0] + b.x + (float)r.v[0], 0.f);
+                p.v[1] = (bf16_t)fmaxf(acc2[j][i][1] + b.y + (float)r.v[1], 0.f);
+                p.v[2] = (bf16_t)fmaxf(acc2[j][i][2] + b.z + (float)r.v[2], 0.f);
+                p.v[3] = (bf16_t)fmaxf(acc2[j][i][3] + b.w + (float)r.v[3], 0.f);
+                *cell = p;
+            }
+        }
+        __syncthreads();
+        // copy the finished tile out in full 128-byte row segments
+        if (!(a.dbg & 8))
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            const int m = m0 + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(sA3 + (ch >> 2) * BM * 64 + lds_off(row, ch & 3));
+            if (m < a.M) *reinterpret_cast<u32x4*>(a.xout + (long long)m * NOUT + nc * NB + ch * 8) = v;
+        }
+        if constexpr (C2 > 0) {
+            if (!(a.dbg & 16))
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                u32x4 xf[4], wf[TN3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sA3 + kt * BM * 64 + x3_off[i]);
+#pragma unroll
+                for (int j = 0; j < TN3; ++j) wf[j] = *reinterpret_cast<const u32x4*>(sWb + kt * C2 * 64 + wb_off[j]);
+#pragma unroll
+                for (int j = 0; j < TN3; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mma(wf[j], xf[i], acc3[j][i]);
+            }
+        }
+    }
+
+    // ---------------- t1' = relu(acc3 + b1n) -> LDS -> full rows ----------------
+    if constexpr (C2 > 0) {
+        __syncthreads();  // every wave is done with the last chunk's operands: the region is reused for the output tile
+#pragma unroll
+        for (int j = 0; j < TN3; ++j) {
+            const int ch0 = wn * (C2 / 2) + j * 16 + fq * 4;
+            const float4 b = *reinterpret_cast<const float4*>(a.b1n + ch0);
+            const int kt = ch0 >> 5, o = ch0 & 31;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + fr;
+                B4 p;
+                p.v[0] = (bf16_t)fmaxf(acc3[j][i][0] + b.x, 0.f);
+                p.v[1] = (bf16_t)fmaxf(acc3[j][i][1] + b.y, 0.f);
+                p.v[2] = (bf16_t)fmaxf(acc3[j][i][2] + b.z, 0.f);
+                p.v[3] = (bf16_t)fmaxf(acc3[j][i][3] + b.w, 0.f);
+                *reinterpret_cast<B4*>(smem + kt * BM * 64 + lds_off(row, o >> 3) + (o & 7) * 2) = p;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = C2 / 8;  // 16-byte pieces per output row
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 256; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
+            const int m = m0 + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (ch >> 2) * BM * 64 + lds_off(row, ch & 3));
+            if (m < a.M) *reinterpret_cast<u32x4*>(a.t1n + (long long)m * C2 + ch * 8) = v;
+        }
+    }
+}
+
+template <int C, int C2> int launch_fused(FusedArgs& a, hipStream_t s) {
+    a.tiles = (a.M + 127) / 128;
+    static const int dbg = [] { const char* e = getenv("MIC_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    void* rec = mic_prof_open(s, 1, 2.0 * a.M * ((double)9 * C * C + (double)C * 4 * C + (double)4 * C * C2));
+    MIC_LAUNCH((fused_block_kernel<C, C2>), dim3(a.tiles), dim3(256), 0, s, a);
+    return mic_prof_close(rec, s);
+}
+
+}  // namespace
+
+extern "C" int mic_bottleneck_fused_supported(int dtype, int C, int C2) {
+    return dtype == MIC_BF16 && ((C == 64 && (C2 == 0 || C2 == 64 || C2 == 128)) || (C == 128 && (C2 == 0 || C2 == 128)));
+}
+
+extern "C" int mic_bottleneck_fused(const mic_fused_block_desc* d, void* stream) {
+    MIC_ARG_CHECK(d && d->t1 && d->w2 && d->b2 && d->w3 && d->b3 && d->res && d->xout, "mic_bottleneck_fused: null pointer");
+    MIC_ARG_CHECK(mic_bottleneck_fused_supported(d->dtype, d->C, d->C2), "mic_bottleneck_fused: unsupported (dtype %d, C=%d, C2=%d)", d->dtype,
+                  d->C, d->C2);
+    MIC_ARG_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && (int64_t)d->B * d->H * d->W < (1ll << 31), "mic_bottleneck_fused: bad geometry %dx%dx%d",
+                  d->B, d->H, d->W);
+    MIC_ARG_CHECK(d->C2 == 0 || (d->w1n && d->b1n && d->t1n), "mic_bottleneck_fused: the fused next convolution needs w1n, b1n and t1n");
+    MIC_ARG_CHECK(d->w2_rows >= 128 && d->w3_rows >= 4 * d->C && (d->C2 == 0 || d->w1n_rows >= 128),
+                  "mic_bottleneck_fused: weight matrices shorter than the kernel reads (w2 %d rows, w3 %d, w1n %d)", d->w2_rows, d->w3_rows,
+                  d->w1n_rows);
+    const uintptr_t al = (uintptr_t)d->t1 | (uintptr_t)d->w2 | (uintptr_t)d->w3 | (uintptr_t)d->res | (uintptr_t)d->xout | (uintptr_t)d->b2 |
+                         (uintptr_t)d->b3 | (uintptr_t)d->w1n | (uintptr_t)d->b1n | (uintptr_t)d->t1n;
+    MIC_ARG_CHECK((al & 15) == 0, "mic_bottleneck_fused: every pointer must be 16-byte aligned");
+    MIC_ARG_CHECK(d->res != (const void*)d->xout && d->t1 != (const void*)d->t1n, "mic_bottleneck_fused: outputs must not alias inputs");
+    FusedArgs a{};
+    a.t1 = (const bf16_t*)d->t1; a.w2 = (const bf16_t*)d->w2; a.b2 = d->b2; a.w3 = (const bf16_t*)d->w3; a.b3 = d->b3;
+    a.res = (const bf16_t*)d->res; a.xout = (bf16_t*)d->xout; a.w1n = (const bf16_t*)d->w1n; a.b1n = d->b1n; a.t1n = (bf16_t*)d->t1n;
+    a.M = d->B * d->H * d->W; a.IH = d->H; a.IW = d->W;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->C == 64) {
+        if (d->C2 == 0) return launch_fused<64, 0>(a, s);
+        if (d->C2 == 64) return launch_fused<64, 64>(a, s);
+        return launch_fused<64, 128>(a, s);
+    }
+    if (d->C2 == 0) return launch_fused<128, 0>(a, s);
+    return launch_fused<128, 128>(a, s);
+}

@@ -473,6 +473,33 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 std::atomic<bool> g_prof_on{false};  // read outside the lock by every launch
 
+}  // namespace
+
+void* mic_prof_open(hipStream_t s, int slot, double flops) {
+    if (!g_prof_on) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap != hipStreamCaptureStatusNone) return nullptr;
+    ProfRec* rec = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_on && g_prof_used < g_prof.size()) {
+            rec = &g_prof[g_prof_used++];
+            rec->slot = slot;
+            rec->flops = flops;
+        }
+    }
+    if (rec && hipEventRecord(rec->e0, s) != hipSuccess) return nullptr;
+    return rec;
+}
+
+int mic_prof_close(void* rec, hipStream_t s) {
+    if (rec) MIC_HIP_CHECK(hipEventRecord(static_cast<ProfRec*>(rec)->e1, s));
+    return 0;
+}
+
+namespace {
+
 template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false>
 int launch(IgemmArgs& a, hipStream_t s, double flops) {
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -480,21 +507,9 @@ int launch(IgemmArgs& a, hipStream_t s, double flops) {
     const int grid = a.tiles_m * a.tiles_n;
     constexpr int kstage = KT * 64 / (int)sizeof(T);
     a.nk = (a.Kt + kstage - 1) / kstage;
-    ProfRec* rec = nullptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (g_prof_on) (void)hipStreamIsCapturing(s, &cap);
-    if (g_prof_on && cap == hipStreamCaptureStatusNone) {
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (g_prof_on && g_prof_used < g_prof.size()) {
-            rec = &g_prof[g_prof_used++];
-            rec->slot = (BM >= 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0);  // tiles of 128 rows and more share a slot
-            rec->flops = flops;
-        }
-    }
-    if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e0, s));
+    void* rec = mic_prof_open(s, (BM >= 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0), flops);  // tiles of 128 rows and more share a slot
     MIC_LAUNCH((igemm_kernel<T, BM, BN, KT, WM, WN, RES_PRE, GLDS, NS, SEG2>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
-    if (rec) MIC_HIP_CHECK(hipEventRecord(rec->e1, s));
-    return 0;
+    return mic_prof_close(rec, s);
 }
 
 // Tile variants: (BM, BN, KT).  The heuristic below picks one from the problem shape; the

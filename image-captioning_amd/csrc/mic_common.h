@@ -44,6 +44,12 @@ void mic_set_error(const char* fmt, ...);
         if (rc_ != 0) return rc_; \
     } while (0)
 
+// ---- per-launch event timing shared by the GEMM-class kernels (mic_profile_begin / mic_profile_end) ----
+// open returns NULL when profiling is off, the stream is capturing or the pool is used up; slot = 2 * (tiles
+// of fewer than 128 rows) + (bf16).  close records the closing event.
+void* mic_prof_open(hipStream_t s, int slot, double flops);
+int mic_prof_close(void* rec, hipStream_t s);
+
 // ---- element types ----
 typedef __bf16 bf16_t;
 typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));

@@ -93,6 +93,31 @@ int mic_conv2d(const mic_conv_desc* d, void* stream);
  * for per-variant parity tests.  No reference counterpart. */
 int mic_conv2d_variant(const mic_conv_desc* d, int variant, void* stream);
 
+/* Tail of one ResNet bottleneck and head of the next in ONE launch (bf16), for identity blocks (stride 1, no
+ * shortcut convolution):
+ *     t2  = relu(conv3x3_pad1(t1) + b2)        C -> C channels, kept on chip
+ *     x'  = relu(conv1x1(t2) + b3 + x)         C -> 4C, written to xout (the next block's residual)
+ *     t1' = relu(conv1x1(x') + b1n)            4C -> C2, written to t1n (the next block's 3x3 input); C2 == 0: skipped
+ * i.e. conv2/bn2/relu, conv3/bn3, the residual add and ReLU of torchvision Bottleneck.forward followed by
+ * conv1/bn1/relu of the NEXT Bottleneck (reached from models/encoders/transformer.py:46), BatchNorm folded into
+ * the weights by the host.  Same arithmetic and the same bf16 rounding points as three mic_conv2d launches; what
+ * changes is the memory traffic: t2 never leaves the chip and x' is written once instead of written and re-read.
+ * Activations NHWC; w2 [>=128 rows][9C] with k = (kh*3+kw)*C + c; w3 [4C][C]; w1n [>=128 rows][4C]; biases fp32.
+ * Supported (mic_bottleneck_fused_supported): bf16, (C, C2) in {(64,0), (64,64), (64,128), (128,0), (128,128)}. */
+typedef struct mic_fused_block_desc {
+    const void* t1;       /* [B][H][W][C] */
+    const void* w2; const float* b2;
+    const void* w3; const float* b3;
+    const void* res;      /* [B*H*W][4C] */
+    void* xout;           /* [B*H*W][4C] */
+    const void* w1n; const float* b1n;   /* NULL when C2 == 0 */
+    void* t1n;            /* [B*H*W][C2] */
+    int32_t dtype, B, H, W, C, C2;
+    int32_t w2_rows, w3_rows, w1n_rows;  /* rows the weight matrices really have */
+} mic_fused_block_desc;
+int mic_bottleneck_fused_supported(int dtype, int C, int C2);
+int mic_bottleneck_fused(const mic_fused_block_desc* d, void* stream);
+
 /* Per-launch timing of the GEMM/conv kernel for roofline reports.  Between begin and end every
  * mic_conv2d launch is bracketed by two hipEvents on its stream (no synchronisation).  end waits for
  * the last event and returns, per tile variant v (0: 128x128, 1: 64x64) and dtype d (index 2*v+d),

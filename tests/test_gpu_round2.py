@@ -271,3 +271,59 @@ def test_checkpoint_file_to_captions_on_the_device(amd, tmp_path):
         ref = O.lstm_generate(sd2, "intermediate", f2, 10, None, K)
         caps, none = amd.gen_caption(model2, img, vocab, 10, torch.device(DEV), None, K)
         assert none is None and caps == [vocab.encode_as_words(t) for t in ref]
+
+
+# ------------------------------------------------------------------------------------------------
+# fused bottleneck tail + next head (torchvision Bottleneck.forward via models/encoders/transformer.py:46)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Cm,C2,B,H,Wd", [(64, 0, 3, 14, 14), (64, 64, 3, 14, 14), (64, 128, 2, 9, 11), (128, 0, 2, 9, 11),
+                                         (128, 128, 3, 14, 14), (64, 64, 1, 5, 5), (128, 128, 5, 28, 28)])
+def test_bottleneck_fused_matches_torch(amd, Cm, C2, B, H, Wd):
+    """conv3x3+ReLU -> conv1x1 + residual + ReLU -> next conv1x1 + ReLU in one launch against the same chain in torch
+    fp32 with bf16 rounding at the same three points (what the layer-by-layer path stores)."""
+    L, W = amd._lib, amd.weights
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(Cm + C2 + H)
+    r16 = lambda t: t.to(bf).float()
+    t1 = r16(torch.randn(B, Cm, H, Wd, generator=g).relu())
+    x = r16(torch.randn(B, 4 * Cm, H, Wd, generator=g).relu())
+    w2 = r16(torch.randn(Cm, Cm, 3, 3, generator=g) / math.sqrt(9 * Cm))
+    w3 = r16(torch.randn(4 * Cm, Cm, 1, 1, generator=g) / math.sqrt(Cm))
+    b2, b3 = 0.1 * torch.randn(Cm, generator=g), 0.1 * torch.randn(4 * Cm, generator=g)
+    t2 = r16(F.relu(F.conv2d(t1, w2, b2, 1, 1)))
+    xo = r16(F.relu(F.conv2d(t2, w3, b3) + x))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, bf)
+    d = L.FusedBlockDesc()
+    keep = [nhwc(t1), W.conv_matrix(w2, bf, DEV), b2.to(DEV), W.conv_matrix(w3, bf, DEV), b3.to(DEV), nhwc(x),
+            torch.full((B, H, Wd, 4 * Cm), 7.0, dtype=bf, device=DEV)]
+    d.t1, d.w2, d.b2, d.w3, d.b3, d.res, d.xout = (t.data_ptr() for t in keep)
+    d.dtype, d.B, d.H, d.W, d.C, d.C2 = L.BF16, B, H, Wd, Cm, C2
+    d.w2_rows, d.w3_rows = keep[1].shape[0], keep[3].shape[0]
+    if C2:
+        w1n = r16(torch.randn(C2, 4 * Cm, 1, 1, generator=g) / math.sqrt(4 * Cm))
+        b1n = 0.1 * torch.randn(C2, generator=g)
+        tn = r16(F.relu(F.conv2d(xo, w1n, b1n)))
+        keep += [W.conv_matrix(w1n, bf, DEV), b1n.to(DEV), torch.full((B, H, Wd, C2), 7.0, dtype=bf, device=DEV)]
+        d.w1n, d.b1n, d.t1n = (t.data_ptr() for t in keep[7:])
+        d.w1n_rows = keep[7].shape[0]
+    L.check(L.lib.mic_bottleneck_fused(C.byref(d), L.stream_ptr()), "mic_bottleneck_fused")
+    tol = dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(keep[6].float().cpu().permute(0, 3, 1, 2).numpy(), xo.numpy(), **tol)
+    if C2:
+        np.testing.assert_allclose(keep[9].float().cpu().permute(0, 3, 1, 2).numpy(), tn.numpy(), **tol)
+
+
+def test_bottleneck_fused_rejects_bad_arguments(amd):
+    L = amd._lib
+    d = L.FusedBlockDesc()
+    assert L.lib.mic_bottleneck_fused(C.byref(d), None) == -1
+    assert L.lib.mic_bottleneck_fused_supported(L.F32, 64, 64) == 0 and L.lib.mic_bottleneck_fused_supported(L.BF16, 64, 64) == 1
+    assert L.lib.mic_bottleneck_fused_supported(L.BF16, 256, 0) == 0 and L.lib.mic_bottleneck_fused_supported(L.BF16, 128, 256) == 0
+    t = torch.zeros(1024, dtype=torch.bfloat16, device=DEV)
+    for f in ("t1", "w2", "b2", "w3", "b3", "res", "xout"):
+        setattr(d, f, t.data_ptr())
+    d.dtype, d.B, d.H, d.W, d.C, d.C2 = L.BF16, 1, 2, 2, 64, 0
+    d.w2_rows, d.w3_rows = 64, 256   # w2 not padded to 128 rows
+    assert L.lib.mic_bottleneck_fused(C.byref(d), None) == -1 and b"shorter than the kernel reads" in L.lib.mic_last_error()
+    d.w2_rows = 128
+    assert L.lib.mic_bottleneck_fused(C.byref(d), None) == -1 and b"alias" in L.lib.mic_last_error()  # res == xout
