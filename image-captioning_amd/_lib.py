@@ -47,6 +47,13 @@ class SkinnyDesc(C.Structure):
                 ("relu", i32)]
 
 
+class AttnFusedDesc(C.Structure):
+    _fields_ = [("qkvf", vp), ("kcache", vp), ("vfcache", vp), ("anc", vp), ("x", vp), ("x_ln", LnRef), ("self_b", vp), ("ln1_g", vp),
+                ("ln1_b", vp), ("kf", vp), ("vf", vp), ("c", vp), ("bo", vp), ("y", vp), ("stats_out", vp), ("attn_out", vp),
+                ("ld_attn", i32), ("accumulate", i32), ("attn_scale", f32), ("dtype", i32), ("N", i32), ("H", i32), ("heads", i32),
+                ("S", i32), ("rows_per_image", i32), ("t", i32), ("t_cap", i32)]
+
+
 class BeamState(C.Structure):
     _fields_ = [("score", vp), ("len", vp), ("seq", vp), ("anc", vp)]
 
@@ -93,7 +100,8 @@ FOLD_MAX_HEADS = 2
 
 class TrLayer(C.Structure):
     _fields_ = ([(n, vp) for n in _TR_W + _TR_B + _TR_LN + ["self_out_wf", "cross_out_wf", "ff2_wf", "self_in_wf", "cross_q_wf", "ff1_wf"]]
-                + [("cross_kf_w", vp * FOLD_MAX_HEADS), ("cross_vf_w", vp * FOLD_MAX_HEADS), ("cross_qb_scaled", vp)])
+                + [("cross_kf_w", vp * FOLD_MAX_HEADS), ("cross_vf_w", vp * FOLD_MAX_HEADS), ("cross_qb_scaled", vp),
+                   ("self_qkvf_wf", vp), ("self_qkvf_b", vp), ("self_of_b", vp)])
 
 
 class TrDecoder(C.Structure):
@@ -106,7 +114,8 @@ class TrWorkspace(C.Structure):
                 ("x", vp), ("xt", vp), ("y", vp), ("qkv", vp), ("o", vp), ("ffh", vp), ("logits", vp),
                 ("kcache", vp * MAX_LAYERS), ("vcache", vp * MAX_LAYERS), ("cross_kv", vp * MAX_LAYERS),
                 ("attn", vp), ("top_val", vp), ("top_idx", vp), ("stats", vp * 2),
-                ("cross_kf", vp * MAX_LAYERS), ("cross_vf", vp * MAX_LAYERS), ("cross_c", vp * MAX_LAYERS)]
+                ("cross_kf", vp * MAX_LAYERS), ("cross_vf", vp * MAX_LAYERS), ("cross_c", vp * MAX_LAYERS),
+                ("qkvf", vp), ("vfcache", vp * MAX_LAYERS)]
 
 
 class LstmDecoder(C.Structure):
@@ -155,6 +164,11 @@ SIGNATURES = {
     "mic_cross_attn_folded": (C.c_int, [P(LnRef), vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, f32, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, vp]),
     "mic_cross_fold_bias": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_attn_fused_supported": (C.c_int, [C.c_int] * 6),
+    "mic_attn_fused": (C.c_int, [P(AttnFusedDesc), vp]),
+    "mic_beam_tail_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mic_beam_tail": (C.c_int, [vp, C.c_int, C.c_int, P(BeamState), P(BeamState), vp, vp, vp] + [C.c_int] * 6 + [vp, vp, vp, vp]
+                      + [C.c_int] * 3 + [vp]),
     "mic_lstm_cell": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_gather_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "mic_logsoftmax_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, vp, vp, vp, vp]),

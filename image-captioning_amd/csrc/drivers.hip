@@ -331,7 +331,7 @@ int check_tr(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
     MIC_ARG_CHECK(dec->heads > 0 && dec->H % dec->heads == 0, "transformer driver: heads=%d", dec->heads);
     MIC_ARG_CHECK(ws->N > 0 && ws->t_cap > 0 && ws->S > 0 && ws->rows_per_image > 0 && ws->N % ws->rows_per_image == 0,
                   "transformer driver: bad workspace geometry");
-    MIC_ARG_CHECK(ws->x && ws->xt && ws->y && ws->qkv && ws->o && ws->ffh && ws->logits, "transformer driver: workspace buffers missing");
+    MIC_ARG_CHECK(ws->x && ws->xt && ws->y && ((ws->qkv && ws->o) || ws->qkvf) && ws->ffh && ws->logits, "transformer driver: workspace buffers missing");
     return 0;
 }
 }  // namespace
@@ -375,9 +375,9 @@ mic_ln_ref ln_view(const float* raw, const float* stats, const float* g, const f
 // sub-layer tails store the pre-norm sum y and its row statistics, the next projection and the next
 // residual add normalise on load.  8 launches per layer, none narrower than (N/16) x (H/128) workgroups.
 int tr_step_chained(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
-                    int attn_mode, hipStream_t s) {
+                    int attn_mode, bool skip_embed, hipStream_t s) {
     const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
-    MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
+    if (!skip_embed) MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
     bool plain = true;  // x is ws->x / ws->xt; otherwise x = LN(ws->y; ws->stats[cs]) with (pg, pb)
     int cs = 0;
     const float *pg = nullptr, *pb = nullptr;
@@ -450,25 +450,124 @@ int tr_step_chained(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const
     d.out = ws->logits; d.out_dtype = MIC_F32; d.ldc = dec->vocab;
     return mic_linear_skinny_ex(&d, s);
 }
+
+// One decoder step with both attention sub-layers of a layer in one launch (mic_attn_fused): the self-attention
+// output projection is folded into the cached values, so a layer is 4 launches (packed in-projection, attention,
+// two feed-forward GEMMs) instead of 8, and the LayerNorms ride on their neighbours as in tr_step_chained.
+int tr_step_fused(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
+                  int attn_mode, bool skip_embed, hipStream_t s) {
+    const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers, QW = (2 + dec->heads) * H;
+    if (!skip_embed) MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
+    bool plain = true;  // x is ws->x / ws->xt; otherwise x = LN(ws->y; ws->stats[cs]) with (pg, pb)
+    int cs = 0;
+    const float *pg = nullptr, *pb = nullptr;
+    auto base = [&](const void* wf, const float* bias, int K, int Ncols) {
+        mic_skinny_desc d{};
+        d.wf = wf; d.bias = bias; d.dtype = dt; d.M = N; d.N = Ncols; d.K = K;
+        return d;
+    };
+    auto set_x = [&](mic_skinny_desc& d) {
+        if (plain) { d.x = ws->xt; d.ld_x = H; }
+        else d.x_ln = ln_view(ws->y, ws->stats[cs], pg, pb, H);
+    };
+    for (int l = 0; l < L; ++l) {
+        const mic_tr_layer& Y = dec->layer[l];
+        {
+            mic_skinny_desc d = base(Y.self_qkvf_wf, Y.self_qkvf_b, H, QW);
+            set_x(d);
+            d.out = ws->qkvf; d.out_dtype = MIC_F32; d.ldc = QW;
+            MIC_TRY(mic_linear_skinny_ex(&d, s));
+        }
+        {
+            mic_attn_fused_desc f{};
+            f.qkvf = ws->qkvf; f.kcache = ws->kcache[l]; f.vfcache = ws->vfcache[l]; f.anc = anc;
+            if (plain) f.x = ws->x;
+            else f.x_ln = ln_view(ws->y, ws->stats[cs], pg, pb, H);
+            f.self_b = Y.self_of_b; f.ln1_g = Y.ln1_g; f.ln1_b = Y.ln1_b;
+            f.kf = ws->cross_kf[l]; f.vf = ws->cross_vf[l]; f.c = ws->cross_c[l]; f.bo = Y.cross_out_b;
+            const int ns = plain ? 0 : cs ^ 1;
+            f.y = ws->y; f.stats_out = ws->stats[ns];
+            f.attn_scale = 1.f;
+            if (attn_mode == 1) {
+                f.attn_out = ws->attn + (int64_t)t * S; f.ld_attn = ws->t_cap * S; f.attn_scale = 1.f / (float)L; f.accumulate = l > 0;
+            } else if (attn_mode == 2) {
+                f.attn_out = ws->attn + ((int64_t)l * ws->t_cap + t) * N * S; f.ld_attn = S;
+            }
+            f.dtype = dt; f.N = N; f.H = H; f.heads = dec->heads; f.S = S; f.rows_per_image = ws->rows_per_image; f.t = t; f.t_cap = ws->t_cap;
+            MIC_TRY(mic_attn_fused(&f, s));
+            plain = false; cs = ns; pg = Y.ln2_g; pb = Y.ln2_b;
+        }
+        {
+            mic_skinny_desc d = base(Y.ff1_wf, Y.ff1_b, H, 2 * H);
+            set_x(d);
+            d.out = ws->ffh; d.out_dtype = dt; d.ldc = 2 * H; d.relu = 1;
+            MIC_TRY(mic_linear_skinny_ex(&d, s));
+        }
+        {
+            mic_skinny_desc d = base(Y.ff2_wf, Y.ff2_b, 2 * H, H);
+            d.x = ws->ffh; d.ld_x = 2 * H;
+            d.res_ln = ln_view(ws->y, ws->stats[cs], pg, pb, H);
+            d.out = ws->y; d.out_dtype = MIC_F32; d.ldc = H; d.stats_out = ws->stats[cs ^ 1];
+            MIC_TRY(mic_linear_skinny_ex(&d, s));
+            cs ^= 1; pg = Y.ln3_g; pb = Y.ln3_b;
+        }
+    }
+    mic_skinny_desc d = base(dec->out_wf, dec->out_b, H, dec->vocab);
+    set_x(d);
+    d.out = ws->logits; d.out_dtype = MIC_F32; d.ldc = dec->vocab;
+    return mic_linear_skinny_ex(&d, s);
+}
+
+int chain_max_rows() {
+    static const int v = [] { const char* e = getenv("MIC_CHAIN_MAX_ROWS"); return e ? atoi(e) : 2048; }();
+    return v;
+}
+
+bool chain_ok(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
+    const int H = dec->H;
+    bool chain = ws->N <= chain_max_rows() && ws->stats[0] && ws->stats[1] && dec->out_wf && H % 4 == 0 && H <= 1024;
+    for (int l = 0; l < dec->layers && chain; ++l) {
+        const mic_tr_layer& Y = dec->layer[l];
+        chain = Y.self_in_wf && Y.self_out_wf && Y.cross_q_wf && Y.cross_out_wf && Y.ff1_wf && Y.ff2_wf;
+    }
+    return chain;
+}
 }  // namespace
+
+// Whether a step on (dec, ws) can take the fused-attention path, the temporary ws->qkvf aside (mic_tr_step_static
+// provides that one itself).
+bool mic_tr_fused_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
+    static const bool off = getenv("MIC_NO_ATTN_FUSE") != nullptr;
+    if (off || !chain_ok(dec, ws)) return false;
+    if (!mic_attn_fused_supported(dec->dtype, dec->H, dec->heads, ws->S, ws->rows_per_image, ws->t_cap)) return false;
+    for (int l = 0; l < dec->layers; ++l) {
+        const mic_tr_layer& Y = dec->layer[l];
+        if (!Y.self_qkvf_wf || !Y.self_qkvf_b || !Y.self_of_b || !ws->vfcache[l] || !use_fold(dec, ws, l)) return false;
+    }
+    return true;
+}
+
+int mic_tr_step_impl(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
+                     int attn_mode, bool skip_embed, void* stream);
 
 extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
                            const int32_t* anc, int t, int attn_mode, void* stream) {
+    return mic_tr_step_impl(dec, ws, tokens, ld_tok, anc, t, attn_mode, false, stream);
+}
+
+int mic_tr_step_impl(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
+                     int attn_mode, bool skip_embed, void* stream) {
     MIC_TRY(check_tr(dec, ws));
     MIC_ARG_CHECK(tokens && t >= 0 && t < ws->t_cap && t < dec->pos_rows, "mic_tr_step: position %d outside t_cap=%d / table=%d", t,
                   ws->t_cap, dec->pos_rows);
     MIC_ARG_CHECK(attn_mode == 0 || ws->attn, "mic_tr_step: attention requested without a buffer");
     hipStream_t s = (hipStream_t)stream;
     const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
-    static const int chain_max = [] { const char* e = getenv("MIC_CHAIN_MAX_ROWS"); return e ? atoi(e) : 2048; }();
-    bool chain = N <= chain_max && ws->stats[0] && ws->stats[1] && dec->out_wf && H % 4 == 0 && H <= 1024;
-    for (int l = 0; l < L && chain; ++l) {
-        const mic_tr_layer& Y = dec->layer[l];
-        chain = Y.self_in_wf && Y.self_out_wf && Y.cross_q_wf && Y.cross_out_wf && Y.ff1_wf && Y.ff2_wf;
-    }
-    if (chain) return tr_step_chained(dec, ws, tokens, ld_tok, anc, t, attn_mode, s);
+    if (ws->qkvf && mic_tr_fused_eligible(dec, ws)) return tr_step_fused(dec, ws, tokens, ld_tok, anc, t, attn_mode, skip_embed, s);
+    MIC_ARG_CHECK(ws->qkv && ws->o, "mic_tr_step: this shape does not take the fused-attention step and needs the qkv and o buffers");
+    if (chain_ok(dec, ws)) return tr_step_chained(dec, ws, tokens, ld_tok, anc, t, attn_mode, skip_embed, s);
     const bool fused = mic_linear_res_ln_supported(H) != 0;
-    MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
+    if (!skip_embed) MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
     for (int l = 0; l < L; ++l) {
         const mic_tr_layer& Y = dec->layer[l];
         // masked self-attention over the cache + residual + LayerNorm
@@ -502,11 +601,21 @@ extern "C" int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspa
     MIC_ARG_CHECK(st && parent && live_images && sqrt_tab && ws->top_val && ws->top_idx, "mic_tr_beam_steps: null pointer");
     MIC_ARG_CHECK(B * K == ws->N && ws->rows_per_image == K, "mic_tr_beam_steps: workspace rows %d != B*K = %d*%d", ws->N, B, K);
     MIC_ARG_CHECK(t0 >= 0 && t1 >= t0 && t1 + 1 <= ws->t_cap, "mic_tr_beam_steps: steps [%d,%d) do not fit t_cap=%d", t0, t1, ws->t_cap);
+    MIC_ARG_CHECK(t1 <= dec->pos_rows, "mic_tr_beam_steps: steps [%d,%d) reach past the position table (%d rows)", t0, t1, dec->pos_rows);
+    // log-softmax + top-K, selection and the next step's embedding as one launch per image where the shape allows
+    static const bool no_tail = getenv("MIC_NO_BEAM_TAIL") != nullptr;
+    const bool tail = !no_tail && mic_beam_tail_supported(K, dec->vocab) && dec->H % 4 == 0;
     auto body = [&](void* stream) -> int {
         for (int t = t0; t < t1; ++t) {
             const mic_beam_state* cur = &st[t & 1];
             const mic_beam_state* nxt = &st[(t + 1) & 1];
-            MIC_TRY(mic_tr_step(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, stream));
+            MIC_TRY(mic_tr_step_impl(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, tail && t > t0, stream));
+            if (tail) {
+                MIC_TRY(mic_beam_tail(ws->logits, dec->vocab, dec->vocab, cur, nxt, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t,
+                                      ws->t_cap, eos_id, t + 1 < t1 ? dec->tok_emb : nullptr, dec->pos_emb, ws->x, ws->xt, dec->dtype, dec->H,
+                                      dec->vocab, stream));
+                continue;
+            }
             MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, ws->N, dec->vocab, K, 1.0f, 0, ws->top_val, ws->top_idx, nullptr, stream));
             MIC_TRY(mic_beam_select(cur, nxt, ws->top_val, ws->top_idx, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t,
                                     ws->t_cap, eos_id, 0, stream));

@@ -50,6 +50,10 @@ void mic_set_error(const char* fmt, ...);
 void* mic_prof_open(hipStream_t s, int slot, double flops);
 int mic_prof_close(void* rec, hipStream_t s);
 
+// ---- decoder-step internals shared between the drivers ----
+// whether a step on (dec, ws) can take the fused-attention path, the temporary ws->qkvf aside
+bool mic_tr_fused_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
+
 // ---- element types ----
 typedef __bf16 bf16_t;
 typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));

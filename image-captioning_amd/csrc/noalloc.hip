@@ -46,8 +46,17 @@ extern "C" int mic_tr_step_static(const mic_tr_decoder* dec, const mic_tr_worksp
     MIC_ARG_CHECK(dec->dtype == MIC_F32 || dec->dtype == MIC_BF16, "mic_tr_step_static: bad dtype");
     MIC_ARG_CHECK(io->N > 0 && dec->H > 0, "mic_tr_step_static: bad sizes N=%d H=%d", io->N, dec->H);
     const int64_t N = io->N, H = dec->H, sz = (int64_t)mic_dtype_size(dec->dtype), parts = (H + 127) / 128;
-    // x, xt, y, qkv, o, ffh, stats[0], stats[1], each starting on a 256-byte boundary
-    const int64_t bytes[8] = {N * H * 4, N * H * sz, N * H * 4, N * 3 * H * 4, N * H * sz, N * 2 * H * sz, N * parts * 8, N * parts * 8};
+    // x, xt, y, the packed in-projection output, o, ffh, stats[0], stats[1], each starting on a 256-byte boundary.  The
+    // fused-attention step (taken when the caller's workspace carries the folded value caches) has a wider packed
+    // projection (q | k | folded values) and no separate attention output.
+    MIC_ARG_CHECK(dec->layers >= 1 && dec->layers <= MIC_MAX_LAYERS, "mic_tr_step_static: %d layers (max %d)", dec->layers, MIC_MAX_LAYERS);
+    unsigned char* base = nullptr;
+    MIC_TRY(scratch_base(&base));
+    mic_tr_workspace ws = *io;
+    ws.stats[0] = ws.stats[1] = (float*)base;  // present for the path decision; placed for real below
+    const bool fused = mic_tr_fused_eligible(dec, &ws);
+    const int64_t bytes[8] = {N * H * 4, N * H * sz, N * H * 4, fused ? N * (2 + dec->heads) * H * 4 : N * 3 * H * 4,
+                              fused ? 0 : N * H * sz, N * 2 * H * sz, N * parts * 8, N * parts * 8};
     int64_t off[8], need = 0;
     for (int i = 0; i < 8; ++i) {
         off[i] = need;
@@ -56,14 +65,12 @@ extern "C" int mic_tr_step_static(const mic_tr_decoder* dec, const mic_tr_worksp
     MIC_ARG_CHECK(need <= (int64_t)MIC_STATIC_SCRATCH_BYTES,
                   "mic_tr_step_static: %d rows of hidden size %d need %lld bytes of temporaries, the built-in buffer holds %lld",
                   io->N, dec->H, (long long)need, (long long)MIC_STATIC_SCRATCH_BYTES);
-    unsigned char* base = nullptr;
-    MIC_TRY(scratch_base(&base));
-    mic_tr_workspace ws = *io;
     ws.x = (float*)(base + off[0]);
     ws.xt = base + off[1];
     ws.y = (float*)(base + off[2]);
-    ws.qkv = (float*)(base + off[3]);
-    ws.o = base + off[4];
+    ws.qkv = fused ? nullptr : (float*)(base + off[3]);
+    ws.qkvf = fused ? (float*)(base + off[3]) : nullptr;
+    ws.o = fused ? nullptr : base + off[4];
     ws.ffh = base + off[5];
     ws.stats[0] = (float*)(base + off[6]);
     ws.stats[1] = (float*)(base + off[7]);

@@ -247,74 +247,85 @@ struct BeamArgs {
 // other ranks without a winner; it sorts as -infinity instead (ties then fall back to candidate order).
 __device__ __forceinline__ double sane_key(double k) { return k == k ? k : -INFINITY; }
 
-__global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
-    constexpr int CMAX = KMAX * KMAX + KMAX;
-    __shared__ double c_key[CMAX], c_score[CMAX];
-    __shared__ int c_slot[CMAX], c_tok[CMAX];
-    __shared__ int s_fin[KMAX], s_off[KMAX], win[KMAX];
-    const int b = blockIdx.x, lane = threadIdx.x, K = a.K;
+struct SelShared {
+    double c_key[KMAX * KMAX + KMAX], c_score[KMAX * KMAX + KMAX];
+    int c_slot[KMAX * KMAX + KMAX], c_tok[KMAX * KMAX + KMAX];
+    int s_fin[KMAX], s_off[KMAX], win[KMAX];
+};
+
+// Selection for image b by one wave (`act`: this thread belongs to it, `lane` its lane); every thread of the
+// workgroup must call, the barriers are workgroup-wide.  tv / ti: the image's [K][K] top-K values and token ids
+// (global or LDS).  new_tok (LDS, [K], may be null): token appended to each surviving slot, -1 for a finished one.
+__device__ __forceinline__ void beam_select_body(const BeamArgs& a, int b, int lane, bool act, SelShared& sh, const float* tv,
+                                                 const int32_t* ti, int* new_tok) {
+    const int K = a.K;
     const int base = b * K;
     const int ns = a.n_live_slots;
-    if (lane < ns) {
+    if (act && lane < ns) {
         const int len = a.cur.len[base + lane];
-        s_fin[lane] = a.cur.seq[(long long)(base + lane) * a.t_cap + len - 1] == a.eos_id;
+        sh.s_fin[lane] = a.cur.seq[(long long)(base + lane) * a.t_cap + len - 1] == a.eos_id;
     }
     __syncthreads();
     int n_live = 0, n_fin = 0;
-    for (int i = 0; i < ns; ++i) (s_fin[i] ? n_fin : n_live)++;
-    if (lane == 0) {
+    for (int i = 0; i < ns; ++i) (sh.s_fin[i] ? n_fin : n_live)++;
+    if (act && lane == 0) {
         // position of each slot's first candidate in the reference's candidate list
         int off = 0, lv = 0, fn = 0;
         for (int i = 0; i < ns; ++i) {
             if (a.in_place) {
-                s_off[i] = off;
-                off += s_fin[i] ? 1 : K;
+                sh.s_off[i] = off;
+                off += sh.s_fin[i] ? 1 : K;
             } else {
-                s_off[i] = s_fin[i] ? n_live * K + fn : lv * K;
-                (s_fin[i] ? fn : lv)++;
+                sh.s_off[i] = sh.s_fin[i] ? n_live * K + fn : lv * K;
+                (sh.s_fin[i] ? fn : lv)++;
             }
         }
     }
-    if (lane < K) win[lane] = lane;  // every rank has a winner whatever the keys are
+    if (act && lane < K) sh.win[lane] = lane;  // every rank has a winner whatever the keys are
     __syncthreads();
     const int ncand = n_live * K + n_fin;
     // fill candidates: slot i contributes K entries (live) or itself (finished)
-    for (int w = lane; w < ns * K; w += 64) {
-        const int i = w / K, j = w - i * K;
-        const int g = base + i;
-        if (s_fin[i]) {
-            if (j == 0) {
-                const int c = s_off[i];
-                const double sc = a.cur.score[g];
-                c_score[c] = sc;
-                c_key[c] = sane_key(sc / a.sqrt_tab[a.cur.len[g]]);
-                c_slot[c] = i;
-                c_tok[c] = -1;
+    if (act) {
+        for (int w = lane; w < ns * K; w += 64) {
+            const int i = w / K, j = w - i * K;
+            const int g = base + i;
+            if (sh.s_fin[i]) {
+                if (j == 0) {
+                    const int c = sh.s_off[i];
+                    const double sc = a.cur.score[g];
+                    sh.c_score[c] = sc;
+                    sh.c_key[c] = sane_key(sc / a.sqrt_tab[a.cur.len[g]]);
+                    sh.c_slot[c] = i;
+                    sh.c_tok[c] = -1;
+                }
+            } else {
+                const int c = sh.s_off[i] + j;
+                const double sc = a.cur.score[g] + (double)tv[i * K + j];
+                sh.c_score[c] = sc;
+                sh.c_key[c] = sane_key(sc / a.sqrt_tab[a.cur.len[g] + 1]);
+                sh.c_slot[c] = i;
+                sh.c_tok[c] = ti[i * K + j];
             }
-        } else {
-            const int c = s_off[i] + j;
-            const double sc = a.cur.score[g] + (double)a.top_val[(long long)g * K + j];
-            c_score[c] = sc;
-            c_key[c] = sane_key(sc / a.sqrt_tab[a.cur.len[g] + 1]);
-            c_slot[c] = i;
-            c_tok[c] = a.top_idx[(long long)g * K + j];
         }
     }
     __syncthreads();
     // stable descending rank = number of candidates that sort strictly ahead
-    for (int c = lane; c < ncand; c += 64) {
-        const double k = c_key[c];
-        int rank = 0;
-        for (int o = 0; o < ncand; ++o) {
-            const double ko = c_key[o];
-            rank += (ko > k) || (ko == k && o < c);
+    if (act) {
+        for (int c = lane; c < ncand; c += 64) {
+            const double k = sh.c_key[c];
+            int rank = 0;
+            for (int o = 0; o < ncand; ++o) {
+                const double ko = sh.c_key[o];
+                rank += (ko > k) || (ko == k && o < c);
+            }
+            if (rank < K) sh.win[rank] = c;
         }
-        if (rank < K) win[rank] = c;
     }
     __syncthreads();
+    if (!act) return;
     int any_live = 0;
     for (int r = 0; r < K; ++r) {
-        const int c = win[r], i = c_slot[c], tok = c_tok[c];
+        const int c = sh.win[r], i = sh.c_slot[c], tok = sh.c_tok[c];
         const int gs = base + i, gd = base + r;
         const int len = a.cur.len[gs];
         const int32_t* sseq = a.cur.seq + (long long)gs * a.t_cap;
@@ -328,14 +339,149 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
             if (tok >= 0 && lane == 0) da[a.t] = gs;
         }
         if (lane == 0) {
-            a.nxt.score[gd] = c_score[c];
+            a.nxt.score[gd] = sh.c_score[c];
             a.nxt.len[gd] = tok >= 0 ? len + 1 : len;
             if (tok >= 0) dseq[len] = tok;
             a.parent[gd] = gs;
+            if (new_tok) new_tok[r] = tok;
         }
         any_live |= (tok >= 0 && tok != a.eos_id);
     }
     if (lane == 0 && any_live && a.live_images) atomicAdd(a.live_images, 1);
+}
+
+__global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
+    __shared__ SelShared sh;
+    const long long base = (long long)blockIdx.x * a.K;
+    beam_select_body(a, blockIdx.x, threadIdx.x, true, sh, a.top_val + base * a.K, a.top_idx + base * a.K, nullptr);
+}
+
+// The tail of a beam-search step in one launch per image: log-softmax + top-K of the image's K rows of logits (one group
+// of 256 threads per row, the row read from memory once into registers), beam selection by the first wave, and the
+// embedding of the chosen tokens for the next position.  Unfused these are three launches, each a chain of dependent
+// memory round trips behind a kernel boundary on a path that is latency bound.
+struct TailArgs {
+    BeamArgs b;
+    const float* logits;
+    int ld, V;
+    const float *tok_emb, *pos_emb;  // embedding for position b.t + 1 is skipped when tok_emb is null
+    float* x;
+    void* xt;
+    int H, vocab, xt_bf16;
+};
+
+template <int K, int R>
+__global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const TailArgs a) {
+    constexpr int G = K < 4 ? K : 4;
+    __shared__ SelShared sh;
+    __shared__ float red[G][4];
+    __shared__ KV wbest[G][4];
+    __shared__ float tv[K * K];
+    __shared__ int32_t ti[K * K];
+    __shared__ int new_tok[K];
+    const int tid = threadIdx.x, grp = tid >> 8, gt = tid & 255, gw = gt >> 6, lane = tid & 63;
+    const int img = blockIdx.x;
+    auto group_max = [&](float v) {
+        v = wave_max(v);
+        __syncthreads();
+        if (lane == 0) red[grp][gw] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red[grp][0], red[grp][1]), fmaxf(red[grp][2], red[grp][3]));
+    };
+    auto group_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[grp][gw] = v;
+        __syncthreads();
+        return (red[grp][0] + red[grp][1]) + (red[grp][2] + red[grp][3]);
+    };
+    for (int row0 = 0; row0 < K; row0 += G) {
+        const int row = row0 + grp;
+        const bool on = row < K;  // every group runs the same barriers; one without a row works on -infinity
+        const float* x = a.logits + ((long long)img * K + (on ? row : 0)) * a.ld;
+        float raw[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = gt + 256 * r;
+            raw[r] = on && i < a.V ? x[i] : -INFINITY;
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < R; ++r) m = fmaxf(m, raw[r]);
+        m = group_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (on && gt + 256 * r < a.V) s += expf(raw[r] - m);
+        s = group_sum(s);
+        const float logs = logf(s);
+        KV loc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) loc[k] = KV{-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = gt + 256 * r;
+            if (on && i < a.V) {
+                KV c{(raw[r] - m) - logs, i};
+                if (before(c, loc[K - 1])) {
+                    loc[K - 1] = c;
+#pragma unroll
+                    for (int k = K - 1; k > 0; --k) {
+                        if (before(loc[k], loc[k - 1])) {
+                            const KV t = loc[k - 1];
+                            loc[k - 1] = loc[k];
+                            loc[k] = t;
+                        }
+                    }
+                }
+            }
+        }
+        for (int r = 0; r < K; ++r) {
+            const KV wb = wave_best(loc[0]);
+            if (lane == 0) wbest[grp][gw] = wb;
+            __syncthreads();
+            KV best = wbest[grp][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (before(wbest[grp][w], best)) best = wbest[grp][w];
+            if (on) {
+                if (loc[0].idx == best.idx && best.idx != 0x7fffffff) {  // this thread owned the winner: emit and pop
+                    tv[row * K + r] = best.key;
+                    ti[row * K + r] = best.idx;
+#pragma unroll
+                    for (int k = 0; k < K - 1; ++k) loc[k] = loc[k + 1];
+                    loc[K - 1] = KV{-INFINITY, 0x7fffffff};
+                } else if (best.idx == 0x7fffffff && gt == 0) {  // fewer than K entries in the row
+                    tv[row * K + r] = -INFINITY;
+                    ti[row * K + r] = 0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    beam_select_body(a.b, img, lane, tid < 64, sh, tv, ti, new_tok);
+    if (!a.tok_emb) return;
+    __syncthreads();
+    const int hv = a.H >> 2, pos = a.b.t + 1;
+    for (int i = tid; i < K * hv; i += 256 * G) {
+        const int r = i / hv, c = (i - r * hv) << 2;
+        int id = new_tok[r];
+        id = id < 0 ? a.b.eos_id : id;  // a finished beam's row is never looked at again: any valid token serves
+        id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+        float4 v = *reinterpret_cast<const float4*>(a.tok_emb + (long long)id * a.H + c);
+        const float4 p = *reinterpret_cast<const float4*>(a.pos_emb + (long long)pos * a.H + c);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        const long long n = (long long)img * K + r;
+        if (a.x) *reinterpret_cast<float4*>(a.x + n * a.H + c) = v;
+        if (a.xt) {
+            if (a.xt_bf16) {
+                bf16_t* o = (bf16_t*)a.xt + n * a.H + c;
+                o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+            } else {
+                *reinterpret_cast<float4*>((float*)a.xt + n * a.H + c) = v;
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void beam_finalize_kernel(const mic_beam_state st, const double* __restrict__ sqrt_tab, int B, int K,
@@ -428,6 +574,35 @@ extern "C" int mic_beam_select(const mic_beam_state* cur, const mic_beam_state* 
     a.sqrt_tab = sqrt_tab; a.B = B; a.K = K; a.n_live_slots = n_live_slots; a.t = t; a.t_cap = t_cap; a.eos_id = eos_id;
     a.in_place = finished_in_place;
     MIC_LAUNCH(beam_select_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    return 0;
+}
+
+extern "C" int mic_beam_tail_supported(int K, int V) { return K >= 1 && K <= KMAX && V >= 1 && V <= 256 * 16; }
+
+extern "C" int mic_beam_tail(const float* logits, int ld, int V, const mic_beam_state* cur, const mic_beam_state* nxt, int32_t* parent,
+                             int32_t* live_images, const double* sqrt_tab, int B, int K, int n_live_slots, int t, int t_cap, int eos_id,
+                             const float* tok_emb, const float* pos_emb, float* x, void* xt, int dtype, int H, int vocab, void* stream) {
+    MIC_ARG_CHECK(logits && cur && nxt && parent && sqrt_tab, "mic_beam_tail: null pointer");
+    MIC_ARG_CHECK(cur->score && cur->len && cur->seq && nxt->score && nxt->len && nxt->seq, "mic_beam_tail: null state");
+    MIC_ARG_CHECK((cur->anc == nullptr) == (nxt->anc == nullptr), "mic_beam_tail: anc must be set in both states or neither");
+    MIC_ARG_CHECK(B > 0 && mic_beam_tail_supported(K, V) && ld >= V, "mic_beam_tail: B=%d K=%d V=%d ld=%d (K <= %d, V <= 4096)", B, K, V, ld, KMAX);
+    MIC_ARG_CHECK(n_live_slots >= 1 && n_live_slots <= K, "mic_beam_tail: n_live_slots=%d", n_live_slots);
+    MIC_ARG_CHECK(t >= 0 && t + 2 <= t_cap, "mic_beam_tail: step %d does not fit t_cap=%d", t, t_cap);
+    MIC_ARG_CHECK(!tok_emb || (pos_emb && (x || xt) && H > 0 && H % 4 == 0 && vocab > 0 && (dtype == MIC_F32 || dtype == MIC_BF16)),
+                  "mic_beam_tail: the embedding of the next position needs pos_emb, an output and H %% 4 == 0");
+    TailArgs a{};
+    a.b.cur = *cur; a.b.nxt = *nxt; a.b.parent = parent; a.b.live_images = live_images; a.b.sqrt_tab = sqrt_tab;
+    a.b.B = B; a.b.K = K; a.b.n_live_slots = n_live_slots; a.b.t = t; a.b.t_cap = t_cap; a.b.eos_id = eos_id; a.b.in_place = 0;
+    a.logits = logits; a.ld = ld; a.V = V; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x = x; a.xt = xt; a.H = H; a.vocab = vocab;
+    a.xt_bf16 = dtype == MIC_BF16;
+    hipStream_t s = (hipStream_t)stream;
+#define MIC_TAIL_CASE(KK) \
+    case KK: MIC_LAUNCH((beam_tail_kernel<KK, 16>), dim3(B), dim3(256 * (KK < 4 ? KK : 4)), 0, s, a); break;
+    switch (K) {
+        MIC_TAIL_CASE(1) MIC_TAIL_CASE(2) MIC_TAIL_CASE(3) MIC_TAIL_CASE(4)
+        MIC_TAIL_CASE(5) MIC_TAIL_CASE(6) MIC_TAIL_CASE(7) MIC_TAIL_CASE(8)
+    }
+#undef MIC_TAIL_CASE
     return 0;
 }
 

@@ -9,6 +9,7 @@ re-running the prefix, beam bookkeeping on the device in fp64.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
@@ -125,6 +126,11 @@ class ImageCaptioner:
             t["ckf"] = torch.empty(Ly, N // rpi, S, heads, H, dtype=d, device=dev)
             t["cvf"] = torch.empty(Ly, N // rpi, S, heads, H, dtype=d, device=dev)
             t["cc"] = torch.empty(Ly, N // rpi, S, heads, dtype=f32, device=dev)
+        fuse = fold and bool(self.dec.layer[0].self_qkvf_wf) and bool(
+            L.lib.mic_attn_fused_supported(L.dtype_code(d), H, heads, S, rpi, t_cap))
+        if fuse:  # both attentions of a layer in one launch: the cached values carry the output projection
+            t["qkvf"] = torch.empty(N, (2 + heads) * H, dtype=f32, device=dev)
+            t["vfc"] = torch.zeros(Ly, N, t_cap, heads, H, dtype=d, device=dev)
         if attn_mode == 1:
             t["attn"] = torch.zeros(N, t_cap, S, dtype=f32, device=dev)
         elif attn_mode == 2:
@@ -137,6 +143,10 @@ class ImageCaptioner:
             ws.kcache[l], ws.vcache[l], ws.cross_kv[l] = t["kc"][l].data_ptr(), t["vc"][l].data_ptr(), t["ckv"][l].data_ptr()
             if fold:
                 ws.cross_kf[l], ws.cross_vf[l], ws.cross_c[l] = t["ckf"][l].data_ptr(), t["cvf"][l].data_ptr(), t["cc"][l].data_ptr()
+        if fuse:
+            ws.qkvf = t["qkvf"].data_ptr()
+            for l in range(Ly):
+                ws.vfcache[l] = t["vfc"][l].data_ptr()
         ws.attn = t["attn"].data_ptr() if attn_mode else None
         ws.stats[0], ws.stats[1] = t["stats"][0].data_ptr(), t["stats"][1].data_ptr()
         if len(self._ws_cache) > 4 * self.decode_groups:
@@ -166,19 +176,43 @@ class ImageCaptioner:
         if G == 1:
             self._beam_group(feats, max_len, beam_size, tokens, lengths, score, attn, 0)
             return tokens, lengths, score, attn
-        while len(self._side_streams) < G:
+        # group 0 runs on the caller's thread and stream, every other group on a host thread and stream of its own: a
+        # run of decode steps is enqueued at about the rate the GPU consumes it, so groups enqueued one after another
+        # by one thread would also run one after another
+        while len(self._side_streams) < G - 1:
             self._side_streams.append(torch.cuda.Stream(device=dev))
         main = torch.cuda.current_stream(dev)
         ready = main.record_event()
         bounds = [(B * g) // G for g in range(G + 1)]
-        for g in range(G):
+        errors, done = [], [None] * G
+
+        def work(g):
             lo, hi = bounds[g], bounds[g + 1]
-            side = self._side_streams[g]
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                self._beam_group(feats[lo:hi], max_len, beam_size, tokens[lo:hi], lengths[lo:hi], score[lo:hi],
-                                 attn[lo:hi] if return_attn else None, g)
-            main.wait_event(side.record_event())
+            try:
+                if g == 0:
+                    self._beam_group(feats[lo:hi], max_len, beam_size, tokens[lo:hi], lengths[lo:hi], score[lo:hi],
+                                     attn[lo:hi] if return_attn else None, g)
+                    return
+                torch.cuda.set_device(dev)
+                side = self._side_streams[g - 1]
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    self._beam_group(feats[lo:hi], max_len, beam_size, tokens[lo:hi], lengths[lo:hi], score[lo:hi],
+                                     attn[lo:hi] if return_attn else None, g)
+                    done[g] = side.record_event()
+            except BaseException as e:  # re-raised on the calling thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(g,)) for g in range(1, G)]
+        for th in threads:
+            th.start()
+        work(0)
+        for th in threads:
+            th.join()
+        if errors:
+            raise errors[0]
+        for ev in done[1:]:
+            main.wait_event(ev)
         return tokens, lengths, score, attn
 
     def _beam_group(self, feats, max_len, beam_size, tokens, lengths, score, attn, slot):

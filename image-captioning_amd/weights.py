@@ -279,6 +279,21 @@ def build_tr_decoder(sd: SD, heads: int, dtype: torch.dtype, device) -> tuple:
                 Y.cross_kf_w[h] = keep(matrix((wq[h * hd:(h + 1) * hd, :].T * sc).float().contiguous(), dtype, device))
                 Y.cross_vf_w[h] = keep(matrix(wo[:, h * hd:(h + 1) * hd].float().contiguous(), dtype, device))
             Y.cross_qb_scaled = keep(vector((bq * sc).float(), device))
+        if heads <= L.FOLD_MAX_HEADS and H % e == 0:
+            # fold the self-attention output projection into the value rows of the packed in-projection
+            # (mic_attn_fused): v'_h = (W_o[:, head h] W_v[head h, :]) x, and the value bias moves into the output bias
+            wi = sd[p + "self_attention.mha.in_proj_weight"].double()
+            bi = sd[p + "self_attention.mha.in_proj_bias"].double()
+            wo = sd[p + "self_attention.mha.out_proj.weight"].double()
+            bo = sd[p + "self_attention.mha.out_proj.bias"].double()
+            rows, ob = [wi[:2 * H]], bo.clone()
+            for h in range(heads):
+                sl = slice(h * hd, (h + 1) * hd)
+                rows.append(wo[:, sl] @ wi[2 * H:][sl, :])
+                ob += wo[:, sl] @ bi[2 * H:][sl]
+            Y.self_qkvf_wf = keep(frag_matrix(_pad_rows(torch.cat(rows, dim=0).float()), dtype, device))
+            Y.self_qkvf_b = keep(vector(torch.cat([bi[:2 * H], torch.zeros(heads * H, dtype=torch.float64)]).float(), device))
+            Y.self_of_b = keep(vector(ob.float(), device))
         for j, nm in enumerate(("self_attention", "cross_attention", "ff"), start=1):
             setattr(Y, f"ln{j}_g", keep(vector(sd[p + nm + ".layer_norm.weight"], device)))
             setattr(Y, f"ln{j}_b", keep(vector(sd[p + nm + ".layer_norm.bias"], device)))

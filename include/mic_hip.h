@@ -279,6 +279,39 @@ int mic_cross_attn_folded(const mic_ln_ref* x_ln, const void* kf, const void* vf
 /* c[row][h] = q_bias_scaled[h-th slice] . k[row][h-th slice] for `rows` key rows of kv [rows][2H] (k then v). */
 int mic_cross_fold_bias(const void* kv, const float* q_bias_scaled, float* c, int dtype, int rows, int H, int heads, void* stream);
 
+/* Both attention sub-layers of a post-LN decoder layer for one new position in ONE launch, one workgroup per image
+ * (models/transformer.py:81-86 CausalSelfAttention on the newest position, :100 its residual + LayerNorm, :136-140
+ * CrossAttention, its residual; the second LayerNorm is left to the consumer):
+ *     y1 = x + sum_h softmax_p( q_h . k_h[p] / sqrt(d) ) V'_h[p] + self_b,   p over the row's cached positions 0..t
+ *     u  = LayerNorm(y1) * ln1_g + ln1_b
+ *     y  = u + sum_h softmax_s( u . K'_h[s] + c_h[s] ) V'x_h[s] + bo          (cross side: as mic_cross_attn_folded)
+ * with the self-attention output projection folded into the cached values: the caller's packed in-projection yields
+ * qkvf [N][(2+heads)H] fp32 = q | k | v'_0 | .. | v'_{heads-1}, v'_h = (W_o[:, h-th slice] W_v[h-th slice, :]) x, and
+ * self_b = b_o + sum_h W_o[:, h-th slice] b_v[h-th slice] (softmax weights sum to one).  Position t of every row is
+ * appended to kcache [N][t_cap][H] and vfcache [N][t_cap][heads][H] (`dtype`); earlier positions are read through the
+ * ancestry table anc [N][t_cap] (NULL: own row), whose entries must name rows of the same image.  x is either plain
+ * fp32 rows (x) or a LayerNorm view (x_ln; ld == width == H), exactly one of the two.  Writes fp32 y [N][H] (may
+ * alias x_ln.raw) and, when stats_out != NULL, its row statistics per 128 columns (see mic_ln_ref).  attn_out as in
+ * mic_cross_attn_step.  Same mathematics as the three launches it replaces (mic_self_attn_step, the output
+ * projection, mic_cross_attn_folded), re-associated.  Supported (mic_attn_fused_supported): H == 1024 bytes / sizeof
+ * element per row (512 bf16, 256 fp32), 1 or 2 heads, S <= 64, t_cap <= 32, up to MIC_MAX_BEAM rows per image. */
+typedef struct mic_attn_fused_desc {
+    const float* qkvf;
+    void *kcache, *vfcache;
+    const int32_t* anc;
+    const float* x;
+    mic_ln_ref x_ln;
+    const float *self_b, *ln1_g, *ln1_b;
+    const void *kf, *vf;      /* folded cross keys / values [N/rows_per_image][S][heads][H] */
+    const float *c, *bo;
+    float *y, *stats_out, *attn_out;
+    int32_t ld_attn, accumulate;
+    float attn_scale;
+    int32_t dtype, N, H, heads, S, rows_per_image, t, t_cap;
+} mic_attn_fused_desc;
+int mic_attn_fused_supported(int dtype, int H, int heads, int S, int rows_per_image, int t_cap);
+int mic_attn_fused(const mic_attn_fused_desc* d, void* stream);
+
 /* LSTM cell pointwise part, gate order i,f,g,o (nn.LSTM, models/basic.py:48,
  * models/intermediate.py:63): c' = s(f)*c + s(i)*tanh(g); h' = s(o)*tanh(c').  gates fp32
  * [N][4*Hd]; c, h fp32 [N][Hd] updated in place; h' is also written in `dtype` to ht0 (row stride
@@ -329,6 +362,16 @@ int mic_beam_select(const mic_beam_state* cur, const mic_beam_state* nxt, const 
                     const int32_t* top_idx, int32_t* parent, int32_t* live_images,
                     const double* sqrt_tab, int B, int K, int n_live_slots, int t, int t_cap,
                     int eos_id, int finished_in_place, void* stream);
+
+/* The tail of one transformer beam-search step in ONE launch per image: mic_logsoftmax_topk (inv_temp 1) over the
+ * image's K rows of logits [B*K][ld], mic_beam_select (finished_in_place == 0) on the result, and, when tok_emb != NULL,
+ * mic_embed_pos of the tokens just chosen for position t + 1 into x (fp32 [B*K][H]) / xt (`dtype`), i.e. the first
+ * kernel of the next step (models/transformer.py:610-628, then :602 of the next iteration).  A finished beam's row is
+ * embedded with the end token (its row is never read again).  Supported: K <= MIC_MAX_BEAM, V <= 4096. */
+int mic_beam_tail_supported(int K, int V);
+int mic_beam_tail(const float* logits, int ld, int V, const mic_beam_state* cur, const mic_beam_state* nxt, int32_t* parent,
+                  int32_t* live_images, const double* sqrt_tab, int B, int K, int n_live_slots, int t, int t_cap, int eos_id,
+                  const float* tok_emb, const float* pos_emb, float* x, void* xt, int dtype, int H, int vocab, void* stream);
 
 /* Best beam per image (first maximum of score/sqrt(len), models/transformer.py:635-638):
  * tokens [B][t_cap] (-1 padded), lengths [B], score fp32 [B]; if attn_hist != NULL
@@ -433,6 +476,12 @@ typedef struct mic_tr_layer {
     const void* cross_kf_w[2];
     const void* cross_vf_w[2];
     const float* cross_qb_scaled;
+    /* optional, for at most MIC_FOLD_MAX_HEADS heads: the self-attention in-projection with the output projection
+     * folded into the value rows, in fragment order: rows [W_q ; W_k ; W_o[:, head 0] W_v[head 0] ; ...] ((2+heads)H rows,
+     * padded to 128), its bias [b_q ; b_k ; 0 ...] and self_of_b = b_o + sum_h W_o[:, head h] b_v[head h].  With them, the
+     * folded cross weights and the workspace buffers qkvf / vfcache the step driver runs mic_attn_fused. */
+    const void* self_qkvf_wf;
+    const float *self_qkvf_b, *self_of_b;
 } mic_tr_layer;
 
 typedef struct mic_tr_decoder {
@@ -467,6 +516,8 @@ typedef struct mic_tr_workspace {
     void* cross_kf[MIC_MAX_LAYERS];   /* optional, each [N/rows_per_image][S][heads][H] dtype: folded keys */
     void* cross_vf[MIC_MAX_LAYERS];   /*           same shape: folded values */
     float* cross_c[MIC_MAX_LAYERS];   /*           [N/rows_per_image][S][heads] fp32 */
+    float* qkvf;                      /* optional, [N][(2+heads)H] fp32: packed q | k | folded values of the new position */
+    void* vfcache[MIC_MAX_LAYERS];    /* optional, each [N][t_cap][heads][H] dtype: folded self-attention values */
 } mic_tr_workspace;
 
 /* Cross-attention keys/values of every layer from image tokens feats [B][S][H] (dtype):
