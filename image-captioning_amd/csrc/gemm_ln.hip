@@ -192,16 +192,25 @@ struct SkinnyArgs {
     int ld_x, ld_res, ldc, M, N, K, relu, out_dtype, col_blocks, xcd_rows;
 };
 
-// mean and 1/sqrt(var + eps) of one row from its per-part (mean, M2) pairs
+// mean and 1/sqrt(var + eps) of one row from its per-part (mean, M2) pairs.  All parts are requested before any is used
+// (a loop with a runtime trip count would wait for each pair in turn: one memory round trip per part); parts past the
+// row's own re-read the last one and are skipped in the merge.
+constexpr int MAX_LN_PARTS = 8;  // rows of up to 1024 columns
 __device__ __forceinline__ void merge_row_stats(const LnRef& l, int m, float& mean, float& rstd) {
-    const float* st = l.stats + (long long)m * l.parts * 2;
+    const float2* st = reinterpret_cast<const float2*>(l.stats) + (long long)m * l.parts;
+    float2 pr[MAX_LN_PARTS];
+#pragma unroll
+    for (int p = 0; p < MAX_LN_PARTS; ++p) pr[p] = st[p < l.parts ? p : l.parts - 1];
     float n = 0.f, mu = 0.f, m2 = 0.f;
-    for (int p = 0; p < l.parts; ++p) {
-        const float nb = (float)min(128, l.width - 128 * p), mb = st[2 * p], sb = st[2 * p + 1];
-        const float nt = n + nb, d = mb - mu;
-        mu += d * (nb / nt);
-        m2 += sb + d * d * (n * nb / nt);
-        n = nt;
+#pragma unroll
+    for (int p = 0; p < MAX_LN_PARTS; ++p) {
+        if (p < l.parts) {
+            const float nb = (float)min(128, l.width - 128 * p), mb = pr[p].x, sb = pr[p].y;
+            const float nt = n + nb, d = mb - mu;
+            mu += d * (nb / nt);
+            m2 += sb + d * d * (n * nb / nt);
+            n = nt;
+        }
     }
     mean = mu;
     rstd = 1.0f / sqrtf(m2 / n + 1e-5f);
@@ -450,7 +459,9 @@ int check_ln_ref(const char* who, const mic_ln_ref& l, int width) {
     MIC_ARG_CHECK(l.stats && l.gamma && l.beta, "%s: LayerNorm view without stats/gamma/beta", who);
     MIC_ARG_CHECK(l.width == width && l.width % 4 == 0 && l.ld >= l.width && l.ld % 4 == 0 && l.parts == (l.width + 127) / 128,
                   "%s: LayerNorm view of width %d (ld %d, %d parts) does not match %d columns", who, l.width, l.ld, l.parts, width);
-    MIC_ARG_CHECK(((uintptr_t)l.raw & 15) == 0 && ((uintptr_t)l.gamma & 15) == 0 && ((uintptr_t)l.beta & 15) == 0, "%s: 16-byte alignment", who);
+    MIC_ARG_CHECK(l.parts <= MAX_LN_PARTS, "%s: LayerNorm view of %d columns (at most %d)", who, l.width, 128 * MAX_LN_PARTS);
+    MIC_ARG_CHECK(((uintptr_t)l.raw & 15) == 0 && ((uintptr_t)l.gamma & 15) == 0 && ((uintptr_t)l.beta & 15) == 0 && ((uintptr_t)l.stats & 7) == 0,
+                  "%s: 16-byte alignment (statistics: 8-byte)", who);
     return 0;
 }
 
@@ -534,7 +545,8 @@ extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) {
     // off once there are still two workgroups per CU (the vocabulary projection)
     static const int forced_mt = [] { const char* e = getenv("MIC_SKINNY_MT"); return e ? atoi(e) : 0; }();
     const long long cbs = (d->N + 127) / 128;
-    int mt = cbs * ((d->M + 31) / 32) >= 512 ? 2 : 1;  // measured: 64-row blocks never win at these sizes
+    static const int mt2_min = [] { const char* e = getenv("MIC_SKINNY_MT2_MIN"); return e ? atoi(e) : 512; }();
+    int mt = cbs * ((d->M + 31) / 32) >= mt2_min ? 2 : 1;  // measured: 64-row blocks never win at these sizes
     if (forced_mt) mt = forced_mt;
     static const int forced_nw = [] { const char* e = getenv("MIC_SKINNY_NW"); return e ? atoi(e) : 0; }();
     // measured inside the captured decode step: eight waves win for 16-row blocks; the 32-row blocks of
