@@ -88,13 +88,29 @@ template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>&
     *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, v);
 }
 
+// Wave-wide reductions on the data-parallel-primitive path of the vector ALU (no LDS crossbar round trips): within each
+// row of 16 lanes by quad permutes and row mirrors, then the four row results are read into scalar registers and combined,
+// so every lane returns the same value.
+#define MIC_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += MIC_DPP_F32(v, 0xB1);   // quad_perm [1,0,3,2]
+    v += MIC_DPP_F32(v, 0x4E);   // quad_perm [2,3,0,1]
+    v += MIC_DPP_F32(v, 0x141);  // row_half_mirror
+    v += MIC_DPP_F32(v, 0x140);  // row_mirror: every lane holds the sum of its row of 16
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, MIC_DPP_F32(v, 0xB1));
+    v = fmaxf(v, MIC_DPP_F32(v, 0x4E));
+    v = fmaxf(v, MIC_DPP_F32(v, 0x141));
+    v = fmaxf(v, MIC_DPP_F32(v, 0x140));
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
