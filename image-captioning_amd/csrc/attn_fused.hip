@@ -45,31 +45,52 @@ struct FusedAttnArgs {
     int accumulate, t, t_cap, S, R, N;
 };
 
-// Sums N values (a power of two, N <= WIDTH) over groups of WIDTH lanes by recursive halving: at every step a lane keeps
-// one half of its values and hands the other half to its partner, so N - 1 (+ log2(WIDTH / N)) cross-lane moves do the
-// work of N * log2(WIDTH).  On return v[0] holds the group's total of the value whose index is returned; the WIDTH / N
-// lanes that differ in their low bits only hold the same one.
-template <int N, int WIDTH> __device__ __forceinline__ int reduce_scatter(float (&v)[N], int lane) {
-    static_assert(N >= 1 && (N & (N - 1)) == 0 && N <= WIDTH && WIDTH <= 64, "reduce_scatter sizes");
-    int idx = 0, o = WIDTH / 2;
+// v of the lane whose number differs in bit O.  Within a row of 16 lanes this is a data-parallel-primitive move of the
+// vector ALU (quad permutes for 1 and 2, a rotation by 8 within the row for 8); the others go through the LDS crossbar.
+template <int O> __device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (O == 1) return MIC_DPP_F32(v, 0xB1);        // quad_perm [1,0,3,2]
+    else if constexpr (O == 2) return MIC_DPP_F32(v, 0x4E);   // quad_perm [2,3,0,1]
+    else if constexpr (O == 8) return MIC_DPP_F32(v, 0x128);  // row_ror:8
+    else return __shfl_xor(v, O, 64);
+}
+
+// One halving step over lane bit O: a lane keeps HALF of its 2 * HALF values and hands the other half to its partner.
+template <int HALF, int O, int N> __device__ __forceinline__ int halve(float (&v)[N], int lane) {
+    const bool up = (lane & O) != 0;
 #pragma unroll
-    for (int n = N; n > 1; n >>= 1) {
-        const bool up = (lane & o) != 0;
-#pragma unroll
-        for (int i = 0; i < n / 2; ++i) {
-            // the two values are made opaque first: otherwise the selects below are turned into one register-array access
-            // with a runtime index, which is lowered to a compare-and-select chain over all N registers
-            float lo = v[i], hi = v[i + n / 2];
-            asm volatile("" : "+v"(lo), "+v"(hi));
-            const float send = up ? lo : hi;
-            const float keep = up ? hi : lo;
-            v[i] = keep + __shfl_xor(send, o, 64);
-        }
-        idx += up ? n / 2 : 0;
-        o >>= 1;
+    for (int i = 0; i < HALF; ++i) {
+        // the two values are made opaque first: otherwise the selects below are turned into one register-array access
+        // with a runtime index, which is lowered to a compare-and-select chain over all N registers
+        float lo = v[i], hi = v[i + HALF];
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        const float send = up ? lo : hi;
+        const float keep = up ? hi : lo;
+        v[i] = keep + lane_xor<O>(send);
     }
-#pragma unroll
-    for (; o > 0; o >>= 1) v[0] += __shfl_xor(v[0], o, 64);
+    return up ? HALF : 0;
+}
+
+// Sums N values (a power of two, N <= WIDTH) over groups of WIDTH lanes by recursive halving, so that N - 1
+// (+ log2(WIDTH / N)) cross-lane moves do the work of N * log2(WIDTH).  The lane bits are used in the order 1, 2, 8, 4,
+// 16, 32: the steps that move the most values are the cheap in-row ones.  On return v[0] holds the group's total of the
+// value whose index is returned; `writer` is true on one lane of those that hold the same total.
+template <int N, int WIDTH> __device__ __forceinline__ int reduce_scatter(float (&v)[N], int lane, bool& writer) {
+    static_assert(N >= 1 && (N & (N - 1)) == 0 && N <= WIDTH && (WIDTH == 32 || WIDTH == 64), "reduce_scatter sizes");
+    int idx = 0;
+    if constexpr (N >= 2) idx += halve<N / 2, 1>(v, lane);
+    if constexpr (N >= 4) idx += halve<N / 4, 2>(v, lane);
+    if constexpr (N >= 8) idx += halve<N / 8, 8>(v, lane);
+    if constexpr (N >= 16) idx += halve<N / 16, 4>(v, lane);
+    if constexpr (N >= 32) idx += halve<N / 32, 16>(v, lane);
+    if constexpr (N >= 64) idx += halve<N / 64, 32>(v, lane);
+    constexpr int used = N >= 64 ? 63 : N >= 32 ? 31 : N >= 16 ? 15 : N >= 8 ? 11 : N >= 4 ? 3 : N >= 2 ? 1 : 0;
+    if constexpr (!(used & 1)) v[0] += lane_xor<1>(v[0]);
+    if constexpr (!(used & 2)) v[0] += lane_xor<2>(v[0]);
+    if constexpr (!(used & 4)) v[0] += lane_xor<4>(v[0]);
+    if constexpr (!(used & 8)) v[0] += lane_xor<8>(v[0]);
+    if constexpr (!(used & 16)) v[0] += lane_xor<16>(v[0]);
+    if constexpr (!(used & 32) && WIDTH == 64) v[0] += lane_xor<32>(v[0]);
+    writer = (lane & (WIDTH - 1) & ~used) == 0;
     return idx;
 }
 
@@ -215,9 +236,10 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
                     }
                 }
             }
-            const int j = reduce_scatter<NJP, LPH>(pv, lane);
+            bool writer;
+            const int j = reduce_scatter<NJP, LPH>(pv, lane, writer);
             const int rr = j / PPW, p = wave + NW * (j % PPW);
-            if ((lane & (LPH / NJP - 1)) == 0 && j < NJ && rr < rn && p < t) sc[(rr * HEADS + hl) * SP + p] = pv[0];
+            if (writer && j < NJ && rr < rn && p < t) sc[(rr * HEADS + hl) * SP + p] = pv[0];
         }
         if (wave < rn) {
             const float* qp = qs + wave * H + lc;
@@ -345,9 +367,10 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
                     for (int e = 0; e < VEC; ++e) v = fmaf(qx[e], to_f32<T>(kx[i][h].v[e]), v);
                     pv[i * HEADS + h] = v;
                 }
-            const int x = reduce_scatter<NX, 64>(pv, lane);
+            bool writer;
+            const int x = reduce_scatter<NX, 64>(pv, lane, writer);
             const int p = wave + NW * (x / HEADS);
-            if ((lane & (64 / NX - 1)) == 0 && rr < rn && p < S) sc[(rr * HEADS + x % HEADS) * SP + p] = pv[0];
+            if (writer && rr < rn && p < S) sc[(rr * HEADS + x % HEADS) * SP + p] = pv[0];
         }
         __syncthreads();
         for (int rh = wave; rh < rn * HEADS; rh += NW) {

@@ -251,20 +251,44 @@ struct SelShared {
     double c_key[KMAX * KMAX + KMAX], c_score[KMAX * KMAX + KMAX];
     int c_slot[KMAX * KMAX + KMAX], c_tok[KMAX * KMAX + KMAX];
     int s_fin[KMAX], s_off[KMAX], win[KMAX];
+    // per live slot, read from the beam state before anything else: length, score, sqrt_tab[len] and sqrt_tab[len + 1]
+    int s_len[KMAX];
+    double s_score[KMAX], s_sq0[KMAX], s_sq1[KMAX];
 };
 
+// What the selection needs of slot `lane` of image b, requested together (two dependent round trips: the length, then the
+// last token and the square roots); the caller parks the values in LDS with slot_store once they are due.
+struct SlotState {
+    int len, last;
+    double score, sq0, sq1;
+};
+__device__ __forceinline__ SlotState slot_load(const BeamArgs& a, int b, int lane) {
+    const int g = b * a.K + lane;
+    SlotState s;
+    s.len = a.cur.len[g];
+    s.score = a.cur.score[g];
+    s.last = a.cur.seq[(long long)g * a.t_cap + s.len - 1];
+    s.sq0 = a.sqrt_tab[s.len];
+    s.sq1 = a.sqrt_tab[s.len + 1];
+    return s;
+}
+__device__ __forceinline__ void slot_store(const BeamArgs& a, SelShared& sh, int lane, const SlotState& s) {
+    sh.s_fin[lane] = s.last == a.eos_id;
+    sh.s_len[lane] = s.len;
+    sh.s_score[lane] = s.score;
+    sh.s_sq0[lane] = s.sq0;
+    sh.s_sq1[lane] = s.sq1;
+}
+
 // Selection for image b by one wave (`act`: this thread belongs to it, `lane` its lane); every thread of the
-// workgroup must call, the barriers are workgroup-wide.  tv / ti: the image's [K][K] top-K values and token ids
+// workgroup must call, the barriers are workgroup-wide.  The caller has run slot_load / slot_store for the first
+// n_live_slots lanes of that wave (no barrier needed in between: the first one below publishes them).  tv / ti: the image's [K][K] top-K values and token ids
 // (global or LDS).  new_tok (LDS, [K], may be null): token appended to each surviving slot, -1 for a finished one.
 __device__ __forceinline__ void beam_select_body(const BeamArgs& a, int b, int lane, bool act, SelShared& sh, const float* tv,
                                                  const int32_t* ti, int* new_tok) {
     const int K = a.K;
     const int base = b * K;
     const int ns = a.n_live_slots;
-    if (act && lane < ns) {
-        const int len = a.cur.len[base + lane];
-        sh.s_fin[lane] = a.cur.seq[(long long)(base + lane) * a.t_cap + len - 1] == a.eos_id;
-    }
     __syncthreads();
     int n_live = 0, n_fin = 0;
     for (int i = 0; i < ns; ++i) (sh.s_fin[i] ? n_fin : n_live)++;
@@ -288,21 +312,20 @@ __device__ __forceinline__ void beam_select_body(const BeamArgs& a, int b, int l
     if (act) {
         for (int w = lane; w < ns * K; w += 64) {
             const int i = w / K, j = w - i * K;
-            const int g = base + i;
             if (sh.s_fin[i]) {
                 if (j == 0) {
                     const int c = sh.s_off[i];
-                    const double sc = a.cur.score[g];
+                    const double sc = sh.s_score[i];
                     sh.c_score[c] = sc;
-                    sh.c_key[c] = sane_key(sc / a.sqrt_tab[a.cur.len[g]]);
+                    sh.c_key[c] = sane_key(sc / sh.s_sq0[i]);
                     sh.c_slot[c] = i;
                     sh.c_tok[c] = -1;
                 }
             } else {
                 const int c = sh.s_off[i] + j;
-                const double sc = a.cur.score[g] + (double)tv[i * K + j];
+                const double sc = sh.s_score[i] + (double)tv[i * K + j];
                 sh.c_score[c] = sc;
-                sh.c_key[c] = sane_key(sc / a.sqrt_tab[a.cur.len[g] + 1]);
+                sh.c_key[c] = sane_key(sc / sh.s_sq1[i]);
                 sh.c_slot[c] = i;
                 sh.c_tok[c] = ti[i * K + j];
             }
@@ -327,7 +350,7 @@ __device__ __forceinline__ void beam_select_body(const BeamArgs& a, int b, int l
     for (int r = 0; r < K; ++r) {
         const int c = sh.win[r], i = sh.c_slot[c], tok = sh.c_tok[c];
         const int gs = base + i, gd = base + r;
-        const int len = a.cur.len[gs];
+        const int len = sh.s_len[i];
         const int32_t* sseq = a.cur.seq + (long long)gs * a.t_cap;
         int32_t* dseq = a.nxt.seq + (long long)gd * a.t_cap;
         for (int p = lane; p < len; p += 64) dseq[p] = sseq[p];
@@ -353,6 +376,7 @@ __device__ __forceinline__ void beam_select_body(const BeamArgs& a, int b, int l
 __global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
     __shared__ SelShared sh;
     const long long base = (long long)blockIdx.x * a.K;
+    if ((int)threadIdx.x < a.n_live_slots) slot_store(a, sh, threadIdx.x, slot_load(a, blockIdx.x, threadIdx.x));
     beam_select_body(a, blockIdx.x, threadIdx.x, true, sh, a.top_val + base * a.K, a.top_idx + base * a.K, nullptr);
 }
 
@@ -381,6 +405,9 @@ __global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const 
     __shared__ int new_tok[K];
     const int tid = threadIdx.x, grp = tid >> 8, gt = tid & 255, gw = gt >> 6, lane = tid & 63;
     const int img = blockIdx.x;
+    // the beam state of the image's slots does not depend on the logits: requested now, parked in LDS after the top-K passes
+    SlotState slot{};
+    if (tid < a.b.n_live_slots) slot = slot_load(a.b, img, tid);
     auto group_max = [&](float v) {
         v = wave_max(v);
         __syncthreads();
@@ -459,6 +486,7 @@ __global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const 
             __syncthreads();
         }
     }
+    if (tid < a.b.n_live_slots) slot_store(a.b, sh, tid, slot);
     beam_select_body(a.b, img, lane, tid < 64, sh, tv, ti, new_tok);
     if (!a.tok_emb) return;
     __syncthreads();
