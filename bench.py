@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 BATCH, IMG, MAX_LEN, BEAM = 256, 224, 30, 3
 V, H, LAYERS, HEADS, POS_ROWS = 3500, 512, 3, 2, 40
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X
+MFMA_F32_PEAK_TFLOPS = 157.3    # f32-input MFMA (= the f32 vector rate)
 
 
 # secondary workloads (parity-test configurations of the same path; the default is the headline one)
@@ -42,6 +43,12 @@ WORKLOADS = {
                    "batch 512 per GPU, bf16; random-init weights"),
     "lstm": dict(batch=64, beam=3, label="configs[1]: ResNet-50 encoder + 2-layer LSTM decoder (intermediate model, E=H=512, V=3500), "
                  "beam=3, max_len=30, 224x224, batch 64 per GPU, bf16; random-init weights"),
+    "basic": dict(batch=8, beam=1, label="configs[0]: basic model (ResNet-50 encoder with avg-pool + Linear, 2-layer LSTM decoder fed the image "
+                  "feature as its first time step, E=H=512, V=3500), greedy, max_len=30, 224x224, batch 8, fp32 (the reference's own "
+                  "CPU-runnable case: its CPU time is cpu_baseline); random-init weights"),
+    "job": dict(batch=256, beam=3, label="configs[4]: transformer model (ResNet-50 encoder + 3-layer transformer decoder, H=512, 2 heads, "
+                "V=3500), beam=3, max_len=30, 224x224, bf16, one job of --job-images synthetic images sharded contiguously over the "
+                "ranks in micro-batches of 256, no collective until one final gather of the token ids; random-init weights"),
 }
 
 
@@ -50,10 +57,11 @@ def build_state(workload: str = "transformer"):
     if workload in ("swin", "swin_t"):
         sd = amd.weights.random_swin_state(0, depths=(2, 2, 6, 2) if workload == "swin_t" else (2, 2, 18, 2))
         sd.update(amd.weights.random_head_state("swin", H, 0, in_dim=768))
-    elif workload == "lstm":
+    elif workload in ("lstm", "basic"):
+        kind = "intermediate" if workload == "lstm" else "basic"
         sd = amd.weights.random_resnet50_state(0)
-        sd.update(amd.weights.random_head_state("intermediate", H, 0))
-        sd.update(amd.weights.random_lstm_state("intermediate", V, H, H, 2, seed=0))
+        sd.update(amd.weights.random_head_state(kind, H, 0))
+        sd.update(amd.weights.random_lstm_state(kind, V, H, H, 2, seed=0))
         return sd
     else:
         sd = amd.weights.random_resnet50_state(0)
@@ -67,54 +75,131 @@ def cpu_baseline(sd, n_images: int, workload: str, beam: int):
     synthetic workload, timed on this host's cores."""
     import torch
     from oracle import captioner_oracle as O
-    threads = min(16, os.cpu_count() or 1)
+    # the box's share of host cores for one GPU is 16 (OMP_NUM_THREADS there); os.cpu_count() reports the whole machine
+    host_cores = os.cpu_count() or 1
+    threads = min(int(os.environ.get("OMP_NUM_THREADS", "16")), host_cores)
     torch.set_num_threads(threads)
     img = torch.randn(n_images, 3, IMG, IMG, generator=torch.Generator().manual_seed(1234))
     t0 = time.perf_counter()
     with torch.no_grad():
         if workload == "lstm":
             O.lstm_generate(sd, "intermediate", O.encoder_intermediate(sd, img), MAX_LEN, None, beam)
+        elif workload == "basic":
+            O.lstm_generate(sd, "basic", O.encoder_basic(sd, img), MAX_LEN, None, beam)
         else:
             feats = (O.encoder_swin if workload in ("swin", "swin_t") else O.encoder_transformer)(sd, img)
             O.transformer_generate(sd, HEADS, feats, MAX_LEN, None, beam)
     dt = time.perf_counter() - t0
-    return {"value": round(n_images / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n_images} images of the same workload (encoder + per-image beam={beam} search with full-prefix "
-                      f"recompute, fp32 torch CPU), {dt:.1f} s"}
+    how = f"per-image beam={beam} search" if beam > 1 else "batched greedy decoding"
+    return {"value": round(n_images / dt, 3), "unit": "images/s", "cores": threads, "host_cpu_count": host_cores, "kind": "port",
+            "sample": f"{n_images} images of the same workload (encoder + {how} with full-prefix "
+                      f"recompute, fp32 torch CPU, {threads} threads of the host's {host_cores} logical CPUs), {dt:.1f} s"}
 
 
 HBM_PEAK_TBS = 8.0  # HBM3E peak of one MI355X
 
 
 def decode_roofline(ms: float, batch: int, beam: int, steps: int, S: int):
-    """Algorithmic bytes of one beam search at bf16 (2 bytes) over `steps` executed steps, N = batch*beam rows:
-    per step the decoder weights once (8 H^2 per layer: packed self in-projection 3, self out-projection 1,
-    feed-forward 4; the cross-attention projections are folded into the per-image keys/values) plus the vocabulary
-    matrix; the folded cross-attention keys and values of every image and layer (heads x the unfolded size); the
-    self-attention cache (read positions 0..t of every row, write one); logits written and read in fp32; and once
-    per search the cross-K/V projection (image tokens read, folded keys/values written)."""
+    """Algorithmic bytes of one beam search at bf16 (2 bytes) over `steps` executed steps, N = batch*beam rows: per step
+    the decoder weights once (12 H^2 per layer: both attentions' projections 8, feed-forward 4) plus the vocabulary
+    matrix; the cross-attention keys and values of every image and layer (2 S H per image and layer); the self-attention
+    cache (read positions 0..t of every row, write one: 2 H each); logits written and read in fp32; and once per search
+    the cross-K/V projection (image tokens read, keys/values written).  `traffic_model` is the same count for the layout
+    the kernels actually use, in which the query / output projections of both attentions are folded into the keys and
+    values (cross keys and values and cached self values `heads` times as wide, 4 H^2 fewer weights per layer)."""
     N, e = batch * beam, 2
-    weights = (LAYERS * 8 * H * H + V * H) * e
-    folded = LAYERS * 2 * batch * S * HEADS * H * e
+    weights = (LAYERS * 12 * H * H + V * H) * e
+    cross = LAYERS * 2 * batch * S * H * e
     cache = sum(LAYERS * 2 * N * H * e * (t + 1) for t in range(steps))  # t reads + 1 write at step t
     logits = 2 * N * V * 4
-    once = batch * S * H * e + folded
-    total = steps * (weights + folded + logits) + cache + once
+    once = batch * S * H * e + cross
+    total = steps * (weights + cross + logits) + cache + once
+    w_f = (LAYERS * (4 + 2 * HEADS) * H * H + V * H) * e  # packed q | k | folded values, feed-forward
+    cross_f = cross * HEADS
+    cache_f = sum(LAYERS * (1 + HEADS) * N * H * e * (t + 1) for t in range(steps))
+    folded_total = steps * (w_f + cross_f + logits) + cache_f + batch * S * H * e + cross + cross_f
     tbs = total / (ms * 1e-3) / 1e12
     return {"bound": "hbm", "phase": "cross-K/V + beam steps + best-beam extraction", "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS,
-            "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4), "ms": round(ms, 3), "algorithmic_bytes": int(total)}
+            "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4), "ms": round(ms, 3), "algorithmic_bytes": int(total),
+            "traffic_model": int(folded_total)}
 
 
 def measured_traffic():
     """HBM bytes per launch of the 128-row-tile bf16 igemm kernels on this workload, from the committed
     rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs of this script; a live
     run cannot collect hardware counters on itself).  None when the summary file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return round(json.load(f)["igemm_bf16_128row_tiles"]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return round(json.load(f)["igemm_bf16_128row_tiles"]["hbm_bytes_per_launch"]), name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def run_job(args, amd, D, model, sd, dev, rank, world, wl):
+    """configs[4]: one job of --job-images images, sharded contiguously over the ranks, micro-batches of 256, nothing
+    exchanged until the final gather (distributed.caption_dataset).  Image i is a function of i alone (one of 1,024 seeded
+    base images plus a small offset), so the result does not depend on the number of ranks; rank 0 checks that on a
+    1,024-image prefix against the single-process schedule."""
+    import torch
+    import torch.distributed as dist
+    n, mb, beam, t_cap = args.job_images, args.batch or wl["batch"], wl["beam"], MAX_LEN + 1
+    P = min(1024, max(1, n))
+    base = torch.randn(P, 3, IMG, IMG, generator=torch.Generator(device=dev).manual_seed(1234), device=dev)
+
+    def make_batch(lo, hi):
+        idx = torch.arange(lo, hi, device=dev)
+        return base[idx % P] + (idx // P).to(torch.float32).view(-1, 1, 1, 1) * 1e-3
+
+    def caption(m, images):
+        tokens, lengths, score, _ = m.beam_search_ids(m.encode(images), MAX_LEN, beam)
+        return tokens, lengths, score
+
+    pool = amd.lanes.Lanes(model, max(1, args.lanes))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    warm = min(n, world * mb * max(2, 2 * len(pool)))  # set-up, not measured: workspaces and captured graphs of every lane
+    D.caption_dataset(model, caption, make_batch, warm, t_cap, mb, pool)
+    fence()
+    t0 = time.perf_counter()
+    tokens, lengths, score = D.caption_dataset(model, caption, make_batch, n, t_cap, mb, pool)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        pre = min(1024, n)
+        ref = [caption(model, make_batch(lo, min(pre, lo + mb))) for lo in range(0, pre, mb)]
+        same = all(torch.equal(torch.cat([r[i] for r in ref]), x[:pre]) for i, x in enumerate((tokens, lengths, score)))
+        lo, hi = D.shard_range(n, 0, world)
+        steps = (hi - lo + mb - 1) // mb
+        weights = torch.arange(1, t_cap + 1, device=dev, dtype=torch.int64)
+        res = {
+            "metric": f"images captioned/sec (224^2, beam={beam}, max_len=30)", "value": round(n / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": steps, "warmup": 0, "ms_per_step": round(elapsed / max(1, steps) * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": wl["label"], "job_images": n, "micro_batch": mb, "micro_batches_per_rank": steps,
+                       "parallelism": f"dp{world}", "lanes_per_gpu": len(pool), "collectives": "one final gather of token ids, lengths, scores",
+                       "executed_decode_steps": int(lengths.max().item()) - 1},
+            "job_seconds": round(elapsed, 3),
+            "prefix_check": {"images": pre, "identical_to_single_process_schedule": bool(same),
+                             "token_checksum": int(((tokens[:pre].to(torch.int64) + 1) * weights).sum().item())},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(res), flush=True)
+        if not same:
+            raise SystemExit("bench.py: the gathered ids of the first images differ from the single-process schedule")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -130,6 +215,7 @@ def main():
                     "region at --lanes 1 (0 skips it, e.g. under a profiler, so that the kernel statistics are those of the timed region's schedule)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="transformer")
     ap.add_argument("--cpu-images", type=int, default=128, help="sample size of the CPU baseline (0 disables it)")
+    ap.add_argument("--job-images", type=int, default=100_000, help="--workload job: images of the whole job, all ranks together")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -158,9 +244,13 @@ def main():
     vocab = amd.Vocabulary.synthetic(V)
     if args.workload == "lstm":
         model = amd.lstm.IntermediateImageCaptioner(vocab, torch.bfloat16, sync_every=MAX_LEN).load_state_dict(sd).to(dev)
+    elif args.workload == "basic":
+        model = amd.lstm.BasicImageCaptioner(vocab, torch.float32, sync_every=MAX_LEN).load_state_dict(sd).to(dev)
     else:
         model = amd.transformer.ImageCaptioner(vocab, HEADS, torch.bfloat16, encoder="swin" if args.workload in ("swin", "swin_t") else "resnet50",
                                                sync_every=MAX_LEN, decode_groups=args.decode_groups).load_state_dict(sd).to(dev)
+    if args.workload == "job":
+        return run_job(args, amd, D, model, sd, dev, rank, world, wl)
     B = args.batch or wl["batch"]
     images = torch.randn(B, 3, IMG, IMG, generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev)
     n_total = B * world
@@ -170,21 +260,24 @@ def main():
     lanes = amd.lanes.Lanes(model, max(3, n_lanes) if args.concurrent_steps > 0 and world == 1 else n_lanes)
 
     def caption(m, _item):
-        feats = m.encoder(images) if args.workload == "lstm" else m.encode(images)
+        if args.workload == "basic":  # batched greedy decoding (models/image_captioner.py:82-105); no scores, PAD after EOS
+            t = m.sample_ids(m.encoder(images), MAX_LEN, None)
+            tokens = torch.nn.functional.pad(t, (0, MAX_LEN + 1 - t.shape[1]), value=-1)
+            return tokens, torch.full((B,), t.shape[1], dtype=torch.int32, device=dev), torch.zeros(B, device=dev)
         if args.workload == "lstm":
-            tokens, lengths = m.beam_search_ids(feats, MAX_LEN, beam)
-            score = torch.zeros(B, device=dev)  # models/image_captioner.py:61-69 returns no scores
-        else:
-            tokens, lengths, score, _ = m.beam_search_ids(feats, MAX_LEN, beam)
+            tokens, lengths = m.beam_search_ids(m.encoder(images), MAX_LEN, beam)
+            return tokens, lengths, torch.zeros(B, device=dev)  # models/image_captioner.py:61-69 returns no scores
+        tokens, lengths, score, _ = m.beam_search_ids(m.encode(images), MAX_LEN, beam)
         return tokens, lengths, score
 
     def run_steps(n, in_flight=n_lanes):
-        """n steps = n whole batches through encoder + search, at most `in_flight` of them at a time; then, in step order
-        on this thread, the gather of every step's ids across ranks."""
-        out = None
-        for tokens, lengths, score in lanes.map(caption, range(n), in_flight):
-            out = D.gather_captions(tokens, lengths, score, n_total)
-        return out
+        """n steps = n whole batches through encoder + search, at most `in_flight` of them at a time; then ONE gather
+        across ranks of the ids of all n steps (nothing is exchanged while the steps run)."""
+        if n == 0:
+            return None
+        parts = [tuple(x.clone() for x in r) for r in lanes.map(caption, range(n), in_flight)]
+        tokens, lengths, score = (torch.cat([q[i] for q in parts]) for i in range(3))
+        return D.gather_captions(tokens, lengths, score, n * n_total)
 
     def fence():
         torch.cuda.synchronize()
@@ -222,7 +315,7 @@ def main():
         concurrent = {"lanes": 3, "steps": n3, "value": round(B * n3 / dt3, 2), "unit": "images/s", "ms_per_step": round(dt3 / n3 * 1e3, 3)}
 
     single = None
-    if rank == 0 and n_lanes > 1:
+    if world == 1 and n_lanes > 1:
         # the same kernels with the GPU to themselves: under concurrent lanes a launch's duration includes the other
         # lanes' work, so the per-kernel reading is taken again on one lane, outside the timed region
         run_steps(1, 1)
@@ -250,8 +343,12 @@ def main():
 
     if rank == 0:
         # dominant kernel: igemm_kernel<bf16> with tiles of 128 rows and more (slot 1), the encoder's implicit-GEMM convolutions
-        k_ms, k_n, k_fl = ms[1], cnt[1], fl[1]
+        # (together with the fused bottleneck launches, which share the slot); the fp32 workload's are in slot 0
+        ks = 0 if args.workload == "basic" else 1
+        k_ms, k_n, k_fl = ms[ks], cnt[ks], fl[ks]
         achieved = (k_fl / k_n) / (k_ms / k_n * 1e-3) / 1e12 if k_n else 0.0
+        peak = MFMA_F32_PEAK_TFLOPS if ks == 0 else MFMA_BF16_PEAK_TFLOPS
+        traffic, traffic_file = measured_traffic()
 
         def igemm_roofline(n, t_ms, flops):
             tf = flops / (t_ms * 1e-3) / 1e12 if n else 0.0
@@ -261,13 +358,15 @@ def main():
             "metric": f"images captioned/sec (224^2, beam={beam}, max_len=30)", "value": round(n_total * args.steps / elapsed, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.workload == "basic" else "bf16", "data": "synthetic",
             "config": {"workload": wl["label"] if B == wl["batch"] else wl["label"].replace(f"batch {wl['batch']}", f"batch {B}"),
                        "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}",
                        "lanes_per_gpu": n_lanes},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16> (all tile variants of 128 rows and more)", "achieved": round(achieved, 2),
-                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "traffic": measured_traffic() if args.workload == "transformer" and B == BATCH else None, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+            "roofline": {"bound": "mfma", "kernel": ("igemm_kernel<f32>" if ks == 0 else "igemm_kernel<bf16> and fused_block_kernel") +
+                         " (the encoder's convolution launches with tiles of 128 rows and more)", "achieved": round(achieved, 2),
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "traffic": traffic if args.workload == "transformer" and B == BATCH else None,
+                         "traffic_unit": f"bytes/launch (rocprofv3 PMC, profiles/{traffic_file})",
                          "launches_per_step": k_n // max(1, args.steps),
                          "avg_launch_us": round(k_ms / k_n * 1e3, 2) if k_n else None,
                          "gflop_per_launch": round(k_fl / k_n / 1e9, 3) if k_n else None,
@@ -283,7 +382,8 @@ def main():
         if decode is not None:
             res["roofline_decode"] = decode
         if args.cpu_images > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(sd, args.cpu_images, args.workload, beam)
+            # configs[0] is timed in full (its batch of 8); the others on a sample of the same workload
+            res["cpu_baseline"] = cpu_baseline(sd, min(args.cpu_images, B) if args.workload == "basic" else args.cpu_images, args.workload, beam)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

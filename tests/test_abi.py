@@ -103,17 +103,22 @@ def test_argument_errors_need_no_gpu():
 
 
 def test_decode_roofline_bytes():
-    """bench.py's search-phase byte count, term by term, at the headline configuration."""
+    """bench.py's search-phase byte count, term by term, at the headline configuration: the algorithmic figure is that of
+    the unfolded layout (what the reference's mathematics needs), the folded layout the kernels use is reported beside it."""
     import bench
     r = bench.decode_roofline(8.0, 256, 3, 30, 49)
-    N, H, V, Lr, e = 768, 512, 3500, 3, 2
-    weights = (Lr * 8 * H * H + V * H) * e
-    folded = Lr * 2 * 256 * 49 * 2 * H * e
+    N, H, V, Lr, e, heads = 768, 512, 3500, 3, 2, 2
+    weights = (Lr * 12 * H * H + V * H) * e
+    cross = Lr * 2 * 256 * 49 * H * e
     cache = Lr * 2 * N * H * e * sum(range(1, 31))
     logits = 2 * N * V * 4
-    total = 30 * (weights + folded + logits) + cache + 256 * 49 * H * e + folded
+    total = 30 * (weights + cross + logits) + cache + 256 * 49 * H * e + cross
     assert r["algorithmic_bytes"] == total
     assert r["unit"] == "TB/s" and abs(r["achieved"] - total / 8e-3 / 1e12) < 1e-3 and r["frac"] == round(r["achieved"] / 8.0, 4)
+    w_f = (Lr * (4 + 2 * heads) * H * H + V * H) * e
+    cache_f = Lr * (1 + heads) * N * H * e * sum(range(1, 31))
+    assert r["traffic_model"] == 30 * (w_f + heads * cross + logits) + cache_f + 256 * 49 * H * e + cross + heads * cross
+    assert r["traffic_model"] > r["algorithmic_bytes"]
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
