@@ -45,6 +45,21 @@ struct IgemmArgs {
 // distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int lds_off(int row, int q) { return row * 64 + ((q ^ (((row >> 3) & 1) << 1)) << 4); }
 
+// x/2 * (1 + erf(x / sqrt 2)) with erf from the rational-exponential form of Abramowitz & Stegun 7.1.26 (absolute error
+// below 1.5e-7, i.e. fp32 rounding of the result), branch-free: erfc(|z|) = poly(t) * exp(-z^2), t = 1 / (1 + p |z|), and
+// 1 + erf(z) is erfc(|z|) for z < 0 (no cancellation in the left tail) and 2 - erfc(|z|) otherwise.  The library erff is a
+// piecewise polynomial with divergent branches and costs several times as much in an epilogue that is otherwise memory bound.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_abs = p * t * __expf(-z * z);
+    return 0.5f * x * (x < 0.f ? erfc_abs : 2.0f - erfc_abs);
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     __device__ static __forceinline__ void run(const uint4& wf, const uint4& xf, f32x4_t& acc) {
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             } else if (a.relu == MIC_ACT_GELU) {  // exact (erf) form, nn.GELU() default
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
             }
             const long long oo = (long long)m * a.ldc + n;
             if (a.out_dtype == MIC_F32) {

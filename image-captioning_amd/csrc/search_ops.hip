@@ -394,16 +394,18 @@ struct TailArgs {
     int H, vocab, xt_bf16;
 };
 
-template <int K, int R>
-__global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const TailArgs a) {
-    constexpr int G = K < 4 ? K : 4;
+// GW threads work on one row of logits (256, or 128 for more than four beams so that every row of the image has a
+// group of its own within the 1024 threads of a workgroup); a thread holds up to 4096 / GW entries of the row in registers.
+template <int K, int GW>
+__global__ __launch_bounds__(GW * (K < 1024 / GW ? K : 1024 / GW)) void beam_tail_kernel(const TailArgs a) {
+    constexpr int G = K < 1024 / GW ? K : 1024 / GW, R = 4096 / GW, NWG = GW / 64;
     __shared__ SelShared sh;
-    __shared__ float red[G][4];
-    __shared__ KV wbest[G][4];
+    __shared__ float red[G][NWG];
+    __shared__ KV wbest[G][NWG];
     __shared__ float tv[K * K];
     __shared__ int32_t ti[K * K];
     __shared__ int new_tok[K];
-    const int tid = threadIdx.x, grp = tid >> 8, gt = tid & 255, gw = gt >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, grp = tid / GW, gt = tid % GW, gw = gt >> 6, lane = tid & 63;
     const int img = blockIdx.x;
     // the beam state of the image's slots does not depend on the logits: requested now, parked in LDS after the top-K passes
     SlotState slot{};
@@ -413,14 +415,18 @@ __global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const 
         __syncthreads();
         if (lane == 0) red[grp][gw] = v;
         __syncthreads();
-        return fmaxf(fmaxf(red[grp][0], red[grp][1]), fmaxf(red[grp][2], red[grp][3]));
+        float m = red[grp][0];
+#pragma unroll
+        for (int w = 1; w < NWG; ++w) m = fmaxf(m, red[grp][w]);
+        return m;
     };
     auto group_sum = [&](float v) {
         v = wave_sum(v);
         __syncthreads();
         if (lane == 0) red[grp][gw] = v;
         __syncthreads();
-        return (red[grp][0] + red[grp][1]) + (red[grp][2] + red[grp][3]);
+        if constexpr (NWG == 4) return (red[grp][0] + red[grp][1]) + (red[grp][2] + red[grp][3]);
+        else return red[grp][0] + red[grp][1];
     };
     for (int row0 = 0; row0 < K; row0 += G) {
         const int row = row0 + grp;
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const 
         float raw[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int i = gt + 256 * r;
+            const int i = gt + GW * r;
             raw[r] = on && i < a.V ? x[i] : -INFINITY;
         }
         float m = -INFINITY;
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const 
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (on && gt + 256 * r < a.V) s += expf(raw[r] - m);
+            if (on && gt + GW * r < a.V) s += expf(raw[r] - m);
         s = group_sum(s);
         const float logs = logf(s);
         KV loc[K];
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const 
         for (int k = 0; k < K; ++k) loc[k] = KV{-INFINITY, 0x7fffffff};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int i = gt + 256 * r;
+            const int i = gt + GW * r;
             if (on && i < a.V) {
                 KV c{(raw[r] - m) - logs, i};
                 if (before(c, loc[K - 1])) {
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const 
             __syncthreads();
             KV best = wbest[grp][0];
 #pragma unroll
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < NWG; ++w)
                 if (before(wbest[grp][w], best)) best = wbest[grp][w];
             if (on) {
                 if (loc[0].idx == best.idx && best.idx != 0x7fffffff) {  // this thread owned the winner: emit and pop
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(256 * (K < 4 ? K : 4)) void beam_tail_kernel(const 
     if (!a.tok_emb) return;
     __syncthreads();
     const int hv = a.H >> 2, pos = a.b.t + 1;
-    for (int i = tid; i < K * hv; i += 256 * G) {
+    for (int i = tid; i < K * hv; i += GW * G) {
         const int r = i / hv, c = (i - r * hv) << 2;
         int id = new_tok[r];
         id = id < 0 ? a.b.eos_id : id;  // a finished beam's row is never looked at again: any valid token serves
@@ -625,7 +631,7 @@ extern "C" int mic_beam_tail(const float* logits, int ld, int V, const mic_beam_
     a.xt_bf16 = dtype == MIC_BF16;
     hipStream_t s = (hipStream_t)stream;
 #define MIC_TAIL_CASE(KK) \
-    case KK: MIC_LAUNCH((beam_tail_kernel<KK, 16>), dim3(B), dim3(256 * (KK < 4 ? KK : 4)), 0, s, a); break;
+    case KK: MIC_LAUNCH((beam_tail_kernel<KK, (KK <= 4 ? 256 : 128)>), dim3(B), dim3(KK <= 4 ? 256 * KK : 128 * KK), 0, s, a); break;
     switch (K) {
         MIC_TAIL_CASE(1) MIC_TAIL_CASE(2) MIC_TAIL_CASE(3) MIC_TAIL_CASE(4)
         MIC_TAIL_CASE(5) MIC_TAIL_CASE(6) MIC_TAIL_CASE(7) MIC_TAIL_CASE(8)

@@ -148,8 +148,8 @@ def _beam_state(L, N, t_cap, g, t, eos, finished_rows=()):
 @pytest.mark.parametrize("K,B,V,t,dtype", [(3, 6, 3500, 4, torch.bfloat16), (5, 4, 3500, 9, torch.bfloat16), (1, 9, 200, 2, torch.float32),
                                             (8, 3, 4096, 6, torch.float32), (3, 5, 777, 0, torch.bfloat16), (4, 3, 1000, 3, torch.float32)])
 def test_beam_tail_equals_the_three_launches(amd, K, B, V, t, dtype):
-    """Same logits, same state: the one-launch tail must leave bit-identical beam state, parents and live count, and the
-    embedding rows of live beams must equal mic_embed_pos on the tokens it chose."""
+    """Same logits, same state: the one-launch tail must leave identical beam state (scores bit for bit up to four beams),
+    parents and live count, and the embedding rows of live beams must equal mic_embed_pos on the tokens it chose."""
     L = amd._lib
     N, t_cap, H, eos = B * K, 16, 64, 2
     g = torch.Generator().manual_seed(50 + K + t)
@@ -188,6 +188,10 @@ def test_beam_tail_equals_the_three_launches(amd, K, B, V, t, dtype):
 
     a, b = run(True), run(False)
     for i in range(6):
+        if i == 0 and K > 4:
+            # beyond four beams a row is summed by 128 threads instead of 256: the log-probabilities agree to fp32 rounding
+            torch.testing.assert_close(a[0], b[0], rtol=1e-6, atol=1e-6)
+            continue
         assert torch.equal(a[i], b[i]), f"state field {i} differs"
     live_rows = a[1] == t + 2  # beams that were extended: their new token sits at position t + 1
     assert live_rows.any()
