@@ -96,10 +96,11 @@ template <int N, int WIDTH> __device__ __forceinline__ int reduce_scatter(float 
 
 constexpr int pow2_at_least(int n) { return n <= 1 ? 1 : 2 * pow2_at_least((n + 1) / 2); }
 
-// MULTI: more rows per image than one group; the groups then run one after another inside the workgroup (the folded
-// cross keys / values are re-requested per group and come from L2 after the first).  Without it the group loop does not
-// exist, so nothing is hoisted out of it and kept alive across the whole kernel.
-template <typename T, int RG, int HEADS, bool MULTI>
+// NG: row groups of an image (more than one when it has more rows than a group takes); they run one after another inside
+// the workgroup, the folded cross keys / values re-requested per group (from L2 after the first).  The group count is a
+// compile-time constant and the loop over groups fully unrolled: a real loop makes the compiler hoist every
+// group-independent value out of it and keep it alive across the whole kernel, which spills.
+template <typename T, int RG, int HEADS, int NG>
 __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) {
     constexpr int VEC = Vec16<T>::N, H = 64 * VEC, PARTS = H / 128, SP = 64, NW = 8, NT = 64 * NW;
     constexpr int PPW = 32 / NW;                  // cached positions per wave and row: 32 positions over the waves
@@ -132,8 +133,10 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
         const float* src = which == 0 ? a.self_b : which == 1 ? a.ln1_g : a.ln1_b;
         *reinterpret_cast<float4*>(vecs + which * H + c4) = *reinterpret_cast<const float4*>(src + c4);
     }
-    for (int r0 = 0; r0 < (MULTI ? R : 1); r0 += RG) {
-        const int rn = !MULTI ? R : R - r0 < RG ? R - r0 : RG;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int r0 = g * RG;
+        const int rn = NG == 1 ? R : R - r0 < RG ? R - r0 : RG;
         const long long n0 = (long long)b * R + r0;
 
         // ---- every load that depends on nothing is requested first ----
@@ -440,25 +443,26 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
     }
 }
 
-template <typename T, int RG, int HEADS, bool MULTI> int launch_fused_attn(const FusedAttnArgs& a, hipStream_t s) {
+template <typename T, int RG, int HEADS, int NG> int launch_fused_attn(const FusedAttnArgs& a, hipStream_t s) {
     constexpr int H = 64 * Vec16<T>::N;
     const size_t lds = sizeof(float) * ((size_t)3 * RG * H + RG * HEADS * 64 + 8 * RG * (size_t)H + 3 * H);
     static std::atomic<bool> granted{false};  // lanes call from several host threads
     if (!granted) {
-        MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<T, RG, HEADS, MULTI>),
+        MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<T, RG, HEADS, NG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         granted = true;
     }
-    MIC_LAUNCH((attn_fused_kernel<T, RG, HEADS, MULTI>), dim3(a.N / a.R), dim3(512), lds, s, a);
+    MIC_LAUNCH((attn_fused_kernel<T, RG, HEADS, NG>), dim3(a.N / a.R), dim3(512), lds, s, a);
     return 0;
 }
 
 template <typename T, int HEADS> int dispatch_fused_attn(const FusedAttnArgs& a, hipStream_t s) {
-    if (a.R == 1) return launch_fused_attn<T, 1, HEADS, false>(a, s);
-    if (a.R == 2) return launch_fused_attn<T, 2, HEADS, false>(a, s);
-    if (a.R == 3) return launch_fused_attn<T, 3, HEADS, false>(a, s);
-    if (a.R == 4) return launch_fused_attn<T, 2, HEADS, true>(a, s);
-    return launch_fused_attn<T, 3, HEADS, true>(a, s);
+    if (a.R == 1) return launch_fused_attn<T, 1, HEADS, 1>(a, s);
+    if (a.R == 2) return launch_fused_attn<T, 2, HEADS, 1>(a, s);
+    if (a.R == 3) return launch_fused_attn<T, 3, HEADS, 1>(a, s);
+    if (a.R == 4) return launch_fused_attn<T, 2, HEADS, 2>(a, s);
+    if (a.R <= 6) return launch_fused_attn<T, 3, HEADS, 2>(a, s);
+    return launch_fused_attn<T, 3, HEADS, 3>(a, s);
 }
 
 }  // namespace
