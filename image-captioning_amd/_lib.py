@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
                 ("stride", i32), ("pad_h", i32), ("pad_w", i32),
                 ("ldc", i32), ("ld_res", i32), ("relu", i32), ("k_valid", i32),
                 ("in2", vp), ("in2_img_stride", i64), ("in2_row_stride", i64),
-                ("in2_pix_stride", i32), ("stride2", i32), ("K2", i32), ("w_rows", i32)]
+                ("in2_pix_stride", i32), ("stride2", i32), ("K2", i32), ("w_rows", i32),
+                ("ln_gamma", vp), ("ln_beta", vp), ("ln_out", vp), ("ld_ln_out", i32)]
 
 
 class FusedBlockDesc(C.Structure):
@@ -137,6 +138,7 @@ SIGNATURES = {
     "mic_version": (C.c_int, []),
     "mic_conv2d": (C.c_int, [P(ConvDesc), vp]),
     "mic_conv2d_variant": (C.c_int, [P(ConvDesc), C.c_int, vp]),
+    "mic_conv2d_ln_supported": (C.c_int, [C.c_int]),
     "mic_bottleneck_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mic_bottleneck_fused": (C.c_int, [P(FusedBlockDesc), vp]),
     "mic_profile_begin": (C.c_int, [C.c_int]),

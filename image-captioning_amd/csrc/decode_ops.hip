@@ -44,24 +44,23 @@ __global__ void layernorm_kernel(const float* x, const float* __restrict__ g, co
     float s = 0.f;
     for (int i = lane * 4; i < H; i += 256) {
         const float4 v = *reinterpret_cast<const float4*>(xr + i);
-        s += (v.x + v.y) + (v.z + v.w);
+        s += ln_sum4(v.x, v.y, v.z, v.w);
     }
     const float mean = wave_sum(s) / (float)H;
     float q = 0.f;
     for (int i = lane * 4; i < H; i += 256) {
         const float4 v = *reinterpret_cast<const float4*>(xr + i);
-        const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, d = v.w - mean;
-        q += (a * a + bb * bb) + (c * c + d * d);
+        q += ln_sq4(v.x, v.y, v.z, v.w, mean);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + 1e-5f);
     for (int i = lane * 4; i < H; i += 256) {
         const float4 v = *reinterpret_cast<const float4*>(xr + i);
         const float4 gg = *reinterpret_cast<const float4*>(g + i), bb = *reinterpret_cast<const float4*>(b + i);
         float4 o;
-        o.x = (v.x - mean) * rstd * gg.x + bb.x;
-        o.y = (v.y - mean) * rstd * gg.y + bb.y;
-        o.z = (v.z - mean) * rstd * gg.z + bb.z;
-        o.w = (v.w - mean) * rstd * gg.w + bb.w;
+        o.x = ln_apply(v.x, mean, rstd, gg.x, bb.x);
+        o.y = ln_apply(v.y, mean, rstd, gg.y, bb.y);
+        o.z = ln_apply(v.z, mean, rstd, gg.z, bb.z);
+        o.w = ln_apply(v.w, mean, rstd, gg.w, bb.w);
         if (res) {  // residual-post-norm: the normalised branch is added to the stream (res may alias y)
             const float4 r = *reinterpret_cast<const float4*>(res + (long long)row * H + i);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;

@@ -38,6 +38,11 @@ struct IgemmArgs {
     int K2, Kt;
     long long img_stride2, row_stride2;
     int pix_stride2, stride2;
+    // LayerNorm epilogue (LN variants): out = res + LayerNorm(acc + bias) * ln_g + ln_b in fp32, ln_yt = the same in T
+    const float* ln_g;
+    const float* ln_b;
+    void* ln_yt;
+    int ld_yt;
 };
 
 // LDS tile image: rows of 64 bytes (4 chunks of 16 B).  Chunk q of row r is stored at chunk
@@ -114,7 +119,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
 // SEG2: the K range continues into a second input tensor (see IgemmArgs::in2); compiled in only for
 // the variants the fused bottleneck tails use, because its extra row pointers cost the plain kernels
 // a step of occupancy.
-template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false>
+// LN: the tile spans whole output rows (one n-tile) and the epilogue is LayerNorm over the row followed by the optional
+// residual add; the fp32 tile is staged 32 rows at a time and every wave then owns whole rows, one float4 per lane per 256
+// columns, the summation order of the stand-alone layernorm_kernel (so fusing changes no bit of the result).
+template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false,
+          bool LN = false>
 __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, NT = 64 * NW;  // waves, threads
     constexpr int RW = BM / WM, CW = BN / WN;  // rows / columns per wave
@@ -128,8 +137,9 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
     constexpr int STAGE = KT * (BM + BN) * 64;  // bytes of one stage: KT sub-tiles of X then of W
     // epilogue staging: fp32 accumulators of PASS_ROWS rows, padded rows (conflict-light b128 writes)
     // (one wave-row of the workgroup at a time when a wave owns 64 rows, else the whole tile at once)
-    constexpr int PASS_ROWS = RW >= 64 ? RW : BM;
+    constexpr int PASS_ROWS = LN ? 32 : RW >= 64 ? RW : BM;
     constexpr int LDC_S = BN + 4;
+    static_assert(!LN || (RW % 32 == 0 && !RES_PRE && !SEG2), "LayerNorm epilogue: 32-row passes");
     constexpr int EPI = PASS_ROWS * LDC_S * 4;
     constexpr int SMEM = NS * STAGE > EPI ? NS * STAGE : EPI;
     static_assert(GLDS || NS == 2, "register staging is double-buffered");
@@ -371,9 +381,101 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
     // residual reads and the output store are full-row coalesced 16-byte accesses.
     float* sC = reinterpret_cast<float*>(smem);
     constexpr int NPASS = BM / PASS_ROWS;
+    if constexpr (LN) {
+        constexpr int NJ = (BN + 255) / 256;     // float4 per lane per row
+        constexpr int RPW = PASS_ROWS / NW;      // rows per wave per pass, handled together so their latencies overlap
+        constexpr int PPW = RW / PASS_ROWS;      // passes per wave-row
+        static_assert(PASS_ROWS % NW == 0, "rows per wave");
+        const float fn = (float)a.N;
+        bool ok[NJ];
+        float4 bias4[NJ], g4[NJ], b4[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = lane * 4 + 256 * j;
+            ok[j] = n < a.N && n < BN;
+            const int nc = ok[j] ? n : 0;
+            bias4[j] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            g4[j] = *reinterpret_cast<const float4*>(a.ln_g + nc);
+            b4[j] = *reinterpret_cast<const float4*>(a.ln_b + nc);
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            // the residual rows of this pass are requested before the tile is staged: their latency hides behind it
+            asm volatile("" ::: "memory");  // one pass of residual rows in registers at a time
+            float4 rres[RPW][NJ];
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const int m = m0 + pass * PASS_ROWS + wave + NW * k;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    rres[k][j] = (a.res && ok[j] && m < a.M)
+                                     ? *reinterpret_cast<const float4*>((const float*)a.res + (long long)m * a.ld_res + lane * 4 + 256 * j)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (wm == pass / PPW) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        if (i * 16 / PASS_ROWS != pass % PPW) continue;
+                        const int r = i * 16 % PASS_ROWS + (lane & 15), cidx = wn * CW + j * 16 + (lane >> 4) * 4;
+                        *reinterpret_cast<f32x4_t*>(sC + r * LDC_S + cidx) = acc[j][i];
+                    }
+            }
+            __syncthreads();
+            f32x4_t v[RPW][NJ];
+            float sum[RPW], mean[RPW], q[RPW], rstd[RPW];
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                sum[k] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    v[k][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (ok[j]) {
+                        v[k][j] = *reinterpret_cast<const f32x4_t*>(sC + (wave + NW * k) * LDC_S + lane * 4 + 256 * j);
+                        v[k][j][0] += bias4[j].x; v[k][j][1] += bias4[j].y; v[k][j][2] += bias4[j].z; v[k][j][3] += bias4[j].w;
+                        sum[k] += ln_sum4(v[k][j][0], v[k][j][1], v[k][j][2], v[k][j][3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) mean[k] = wave_sum(sum[k]) / fn;
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                q[k] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (ok[j]) q[k] += ln_sq4(v[k][j][0], v[k][j][1], v[k][j][2], v[k][j][3], mean[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) rstd[k] = 1.0f / sqrtf(wave_sum(q[k]) / fn + 1e-5f);
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const int m = m0 + pass * PASS_ROWS + wave + NW * k;
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (ok[j]) {
+                        const int n = lane * 4 + 256 * j;
+                        float4 o;
+                        o.x = ln_apply(v[k][j][0], mean[k], rstd[k], g4[j].x, b4[j].x) + rres[k][j].x;
+                        o.y = ln_apply(v[k][j][1], mean[k], rstd[k], g4[j].y, b4[j].y) + rres[k][j].y;
+                        o.z = ln_apply(v[k][j][2], mean[k], rstd[k], g4[j].z, b4[j].z) + rres[k][j].z;
+                        o.w = ln_apply(v[k][j][3], mean[k], rstd[k], g4[j].w, b4[j].w) + rres[k][j].w;
+                        if (a.out) *reinterpret_cast<float4*>((float*)a.out + (long long)m * a.ldc + n) = o;
+                        if (a.ln_yt) {
+                            T* t = (T*)a.ln_yt + (long long)m * a.ld_yt + n;
+                            t[0] = from_f32<T>(o.x); t[1] = from_f32<T>(o.y); t[2] = from_f32<T>(o.z); t[3] = from_f32<T>(o.w);
+                        }
+                    }
+            }
+            if (pass + 1 < NPASS) __syncthreads();
+        }
+        return;
+    }
     constexpr int CPR = BN / 8;                    // 8-channel chunks per row
     constexpr int CHUNKS = PASS_ROWS * CPR / NT;  // per thread per pass
-    static_assert((PASS_ROWS * CPR) % NT == 0, "epilogue chunks per thread");
+    static_assert(LN || (PASS_ROWS * CPR) % NT == 0, "epilogue chunks per thread");
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         if (NPASS == 1 || wm == pass) {
@@ -515,7 +617,8 @@ int mic_prof_close(void* rec, hipStream_t s) {
 
 namespace {
 
-template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false>
+template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false,
+          bool LN = false>
 int launch(IgemmArgs& a, hipStream_t s, double flops) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
@@ -523,7 +626,7 @@ int launch(IgemmArgs& a, hipStream_t s, double flops) {
     constexpr int kstage = KT * 64 / (int)sizeof(T);
     a.nk = (a.Kt + kstage - 1) / kstage;
     void* rec = mic_prof_open(s, (BM >= 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0), flops);  // tiles of 128 rows and more share a slot
-    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT, WM, WN, RES_PRE, GLDS, NS, SEG2>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
+    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT, WM, WN, RES_PRE, GLDS, NS, SEG2, LN>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     return mic_prof_close(rec, s);
 }
 
@@ -534,6 +637,13 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
         const char* e = getenv("MIC_IGEMM_FORCE");
         return e ? atoi(e) : -1;
     }();
+    if (a.ln_g) {
+        // whole rows per tile, so the tile width follows N.  Measured on the Swin-V2-S shapes at batch 512 (M = 1.6 M ... 100 k
+        // rows, K = N and 4N): 128-byte stages win for the 128-wide tile, three direct-to-LDS stages for the wider ones.
+        if (a.N <= 128) return launch<T, 128, 128, 2, 4, 2, false, false, 2, false, true>(a, s, flops);
+        if (a.N <= 256) return launch<T, 128, 256, 1, 2, 4, false, true, 3, false, true>(a, s, flops);
+        return launch<T, 128, 384, 1, 2, 4, false, true, 3, false, true>(a, s, flops);
+    }
     const int forced = variant >= 0 ? variant : env_forced;
     int v = forced;
     if (v < 0) {
@@ -625,6 +735,12 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
 }  // namespace
 
 namespace {
+constexpr int LN_MAX_N = 384;  // widest tile of the LayerNorm-epilogue variants
+}
+
+extern "C" int mic_conv2d_ln_supported(int N) { return N > 0 && N % 4 == 0 && N <= LN_MAX_N; }
+
+namespace {
 int conv2d_impl(const mic_conv_desc* d, void* stream, int variant) {
     MIC_ARG_CHECK(d && d->in && d->w && d->out, "mic_conv2d: null pointer");
     MIC_ARG_CHECK(d->dtype == MIC_F32 || d->dtype == MIC_BF16, "mic_conv2d: bad dtype %d", d->dtype);
@@ -653,8 +769,20 @@ int conv2d_impl(const mic_conv_desc* d, void* stream, int variant) {
                           ((uintptr_t)d->in2 & 15) == 0,
                       "mic_conv2d: second input strides / pointer must keep 16-byte alignment");
     }
+    if (d->ln_gamma) {
+        MIC_ARG_CHECK(mic_conv2d_ln_supported(d->N), "mic_conv2d: LayerNorm epilogue needs N %% 4 == 0 and N <= %d, got %d", LN_MAX_N, d->N);
+        MIC_ARG_CHECK(d->ln_beta && d->out_dtype == MIC_F32 && d->relu == MIC_ACT_NONE && !d->in2 && variant < 0,
+                      "mic_conv2d: LayerNorm epilogue takes gamma and beta, an fp32 output, no activation, one K segment and no forced variant");
+        MIC_ARG_CHECK(!d->res || (d->res_dtype == MIC_F32 && d->ld_res % 4 == 0 && ((uintptr_t)d->res & 15) == 0),
+                      "mic_conv2d: LayerNorm epilogue adds an fp32 residual with 16-byte aligned rows");
+        MIC_ARG_CHECK(d->ldc % 4 == 0 && ((uintptr_t)d->out & 15) == 0 && (!d->bias || ((uintptr_t)d->bias & 15) == 0) &&
+                          ((uintptr_t)d->ln_gamma & 15) == 0 && ((uintptr_t)d->ln_beta & 15) == 0,
+                      "mic_conv2d: LayerNorm epilogue needs 16-byte aligned rows and vectors");
+        MIC_ARG_CHECK(!d->ln_out || d->ld_ln_out >= d->N, "mic_conv2d: ld_ln_out=%d < N=%d", d->ld_ln_out, d->N);
+    }
     IgemmArgs a;
     a.in = d->in; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
+    a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.ln_yt = d->ln_out; a.ld_yt = d->ld_ln_out;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.in2 = d->in2; a.K2 = d->in2 ? d->K2 : 0; a.Kt = a.K + a.K2;
     a.img_stride2 = d->in2_img_stride; a.row_stride2 = d->in2_row_stride; a.pix_stride2 = d->in2_pix_stride; a.stride2 = d->stride2;

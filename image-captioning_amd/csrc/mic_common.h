@@ -92,6 +92,19 @@ template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>&
 // row of 16 lanes by quad permutes and row mirrors, then the four row results are read into scalar registers and combined,
 // so every lane returns the same value.
 #define MIC_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+// LayerNorm pieces shared by the stand-alone kernel and the GEMM epilogue: written with explicit fused multiply-adds and
+// contraction switched off, so both compile to the same arithmetic and produce the same bits from the same inputs.
+__device__ __forceinline__ float ln_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
+__device__ __forceinline__ float ln_sq4(float a, float b, float c, float d, float mean) {
+#pragma clang fp contract(off)
+    const float da = a - mean, db = b - mean, dc = c - mean, dd = d - mean;
+    return __builtin_fmaf(da, da, db * db) + __builtin_fmaf(dc, dc, dd * dd);
+}
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float g, float b) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf((v - mean) * rstd, g, b);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v += MIC_DPP_F32(v, 0xB1);   // quad_perm [1,0,3,2]
     v += MIC_DPP_F32(v, 0x4E);   // quad_perm [2,3,0,1]

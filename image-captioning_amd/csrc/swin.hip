@@ -246,6 +246,26 @@ int linear(int dtype, const void* x, int M, int K, const void* w, const float* b
     return mic_conv2d(&d, s);
 }
 
+// y = LayerNorm(x W^T + bias) * g + be (+ res): the normalisation rides in the GEMM epilogue when one tile holds a whole
+// row, else the fp32 product goes through `u` and the stand-alone kernel.  res may be the same buffer as y.
+int linear_ln(int dtype, const void* x, int M, int K, const void* w, const float* bias, const float* g, const float* be,
+              const float* res, float* y, void* yt, int N, float* u, bool fuse, hipStream_t s) {
+    if (fuse && mic_conv2d_ln_supported(N)) {
+        mic_conv_desc d{};
+        d.in = x; d.w = w; d.bias = bias; d.out = y; d.res = res;
+        d.dtype = dtype; d.out_dtype = MIC_F32; d.res_dtype = MIC_F32;
+        d.M = M; d.N = N; d.K = K;
+        d.OH = d.OW = d.IH = d.IW = 1;
+        d.in_img_stride = K; d.in_pix_stride = 4;
+        d.kw_taps = 1; d.run = K; d.stride = 1;
+        d.ldc = N; d.ld_res = N; d.relu = MIC_ACT_NONE;
+        d.ln_gamma = g; d.ln_beta = be; d.ln_out = yt; d.ld_ln_out = N;
+        return mic_conv2d(&d, s);
+    }
+    MIC_TRY(linear(dtype, x, M, K, w, bias, u, MIC_F32, N, MIC_ACT_NONE, s));
+    return res ? mic_layernorm_add(u, g, be, res, y, yt, N, dtype, M, N, s) : mic_layernorm(u, g, be, y, yt, N, dtype, M, N, s);
+}
+
 struct SwinPlan {
     int PH, PW;
     int64_t x, xt, qkv, o, u, h, total;
@@ -351,8 +371,11 @@ extern "C" int mic_swin_forward(const mic_swin* net, const float* images, int B,
     int h = p.PH, w = p.PW, C = net->embed_dim;
     MIC_ARG_CHECK(net->patch_w && net->patch_b && net->patch_g && net->patch_be, "mic_swin_forward: patch embedding not set");
     MIC_TRY(mic_patchify4(images, hbuf, dt, B, H, W, s));
-    MIC_TRY(linear(dt, hbuf, B * h * w, 64, net->patch_w, net->patch_b, u, MIC_F32, C, MIC_ACT_NONE, s));
-    MIC_TRY(mic_layernorm(u, net->patch_g, net->patch_be, x, xt, C, dt, B * h * w, C, s));
+    static const bool fuse_ln = [] {
+        const char* e = getenv("MIC_SWIN_NO_LN_FUSE");  // tuning / comparison runs: LayerNorm as its own launch
+        return !(e && atoi(e));
+    }();
+    MIC_TRY(linear_ln(dt, hbuf, B * h * w, 64, net->patch_w, net->patch_b, net->patch_g, net->patch_be, nullptr, x, xt, C, u, fuse_ln, s));
     int bi = 0;
     for (int st = 0; st < 4; ++st) {
         const int M = B * h * w, heads = net->heads[st];
@@ -363,11 +386,9 @@ extern "C" int mic_swin_forward(const mic_swin* net, const float* images, int B,
             const bool last = st == 3 && k == net->depths[3] - 1;
             MIC_TRY(linear(dt, xt, M, C, Bk.qkv_w, Bk.qkv_b, qkv, dt, 3 * C, MIC_ACT_NONE, s));
             MIC_TRY(mic_window_attn(qkv, Bk.qkv_b, Bk.bias_tab, Bk.logit_scale, o, dt, B, h, w, C, heads, (k & 1) ? WIN / 2 : 0, s));
-            MIC_TRY(linear(dt, o, M, C, Bk.proj_w, Bk.proj_b, u, MIC_F32, C, MIC_ACT_NONE, s));
-            MIC_TRY(mic_layernorm_add(u, Bk.n1_g, Bk.n1_b, x, x, xt, C, dt, M, C, s));
+            MIC_TRY(linear_ln(dt, o, M, C, Bk.proj_w, Bk.proj_b, Bk.n1_g, Bk.n1_b, x, x, xt, C, u, fuse_ln, s));
             MIC_TRY(linear(dt, xt, M, C, Bk.fc1_w, Bk.fc1_b, hbuf, dt, 4 * C, MIC_ACT_GELU, s));
-            MIC_TRY(linear(dt, hbuf, M, 4 * C, Bk.fc2_w, Bk.fc2_b, u, MIC_F32, C, MIC_ACT_NONE, s));
-            MIC_TRY(mic_layernorm_add(u, Bk.n2_g, Bk.n2_b, x, x, last ? out : xt, C, dt, M, C, s));
+            MIC_TRY(linear_ln(dt, hbuf, M, 4 * C, Bk.fc2_w, Bk.fc2_b, Bk.n2_g, Bk.n2_b, x, x, last ? out : xt, C, u, fuse_ln, s));
         }
         if (st < 3) {  // 2x2 neighbourhood -> 4C -> 2C as a 2x2/2 convolution, then LayerNorm
             const mic_swin_merge& Mg = net->merge[st];
@@ -381,9 +402,15 @@ extern "C" int mic_swin_forward(const mic_swin* net, const float* images, int B,
             d.in_img_stride = (int64_t)h * w * C; d.in_row_stride = (int64_t)w * C; d.in_pix_stride = C;
             d.kw_taps = 2; d.run = C; d.stride = 2;
             d.ldc = 2 * C;
+            const bool fused = fuse_ln && mic_conv2d_ln_supported(2 * C);
+            if (fused) {  // the launch reads xt while it writes the normalised rows: they go to the idle attention buffer
+                d.out = x;
+                d.ln_gamma = Mg.g; d.ln_beta = Mg.b; d.ln_out = o; d.ld_ln_out = 2 * C;
+            }
             MIC_TRY(mic_conv2d(&d, s));
+            if (fused) { void* t = xt; xt = o; o = t; }
             h = oh; w = ow; C *= 2;
-            MIC_TRY(mic_layernorm(u, Mg.g, Mg.b, x, xt, C, dt, B * h * w, C, s));
+            if (!fused) MIC_TRY(mic_layernorm(u, Mg.g, Mg.b, x, xt, C, dt, B * h * w, C, s));
         }
     }
     return 0;

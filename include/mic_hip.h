@@ -85,8 +85,20 @@ typedef struct mic_conv_desc {
     int32_t in2_pix_stride, stride2, K2;
     int32_t w_rows;       /* rows the weight matrix really has (0 = not stated): when stated, a matrix shorter than
                              ceil(N/128)*128 rows is rejected instead of being read past its end */
+    /* Optional LayerNorm epilogue (ln_gamma NULL = none), for N the epilogue can hold in one tile (mic_conv2d_ln_supported):
+     *     out[m, :] = res[m, :] + LayerNorm(sum_k A W + bias)[m, :] * ln_gamma + ln_beta      (eps 1e-5, fp32)
+     * and ln_out[m, :] = the same values in `dtype` (NULL = not wanted).  out must be fp32, res fp32 or NULL and may be
+     * the same buffer as out, relu must be MIC_ACT_NONE.  This is the residual-post-norm of a Swin-V2 block,
+     * x = x + norm(branch(x)) (torchvision SwinTransformerBlockV2.forward, reached from models/encoders/swin.py:61-71),
+     * and with res NULL the LayerNorm after the patch embedding and after each patch merge.  The result equals
+     * mic_conv2d with an fp32 output followed by mic_layernorm / mic_layernorm_add bit for bit. */
+    const float* ln_gamma;
+    const float* ln_beta;
+    void* ln_out;
+    int32_t ld_ln_out;
 } mic_conv_desc;
 int mic_conv2d(const mic_conv_desc* d, void* stream);
+int mic_conv2d_ln_supported(int N);
 /* The same layer on a named tile variant instead of the one the shape heuristic picks (0: 128x128, 1: 128x128 with
  * 128-byte stages, 4: 64x64, 8: 128x64, 11: 128x256, 16: 256x256 filled directly into LDS, ...; the list is in
  * csrc/igemm.hip).  Every variant computes the same result for every shape; this entry exists for tuning sweeps and

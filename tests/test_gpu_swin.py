@@ -8,6 +8,8 @@ implicit GEMM, residual-post-norm) computes the same function as that restatemen
 fp32: 1e-3 of the feature scale.  bf16: relative L2 error below 3e-2 (tiny) / 5e-2 (24 blocks).
 """
 
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -165,3 +167,104 @@ def test_swin_gen_caption_end_to_end_fp32(amd):
             caps, lp = amd.gen_caption(model, img, vocab, 12, torch.device(DEV), None, K)
             assert caps == [vocab.encode_as_words(t) for t in ref_tok]
             np.testing.assert_allclose(lp.cpu().numpy(), ref_lp.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def _linear_desc(L, x, wm, bias, out, N):
+    M, K = x.shape
+    d = L.ConvDesc()
+    d.in_, d.w, d.bias, d.out = x.data_ptr(), wm.data_ptr(), bias.data_ptr(), out.data_ptr()
+    d.dtype, d.out_dtype, d.res_dtype = L.dtype_code(x.dtype), L.F32, L.F32
+    d.M, d.N, d.K, d.OH, d.OW, d.IH, d.IW = M, N, K, 1, 1, 1, 1
+    d.in_img_stride, d.in_pix_stride, d.kw_taps, d.run, d.stride = K, 4, 1, K, 1
+    d.ldc, d.ld_res, d.w_rows = N, N, wm.shape[0]
+    return d
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,residual", [
+    (300, 96, 96, True),      # one 128-wide tile, N below it, M tail
+    (1000, 192, 768, True),   # 256-wide tile, long K
+    (257, 384, 384, True),    # 384-wide tile, one row into the third 128-row tile
+    (130, 384, 1536, True),
+    (64, 32, 64, False),      # patch embedding of the tiny configuration: no residual
+    (515, 256, 512, False),   # merge: exactly one 256-wide tile
+    (100, 320, 128, True),    # N between the tile widths
+])
+def test_linear_layernorm_epilogue_equals_the_two_launches(amd, M, N, K, residual, dtype):
+    """x + LayerNorm(GEMM) computed in the GEMM's epilogue is, bit for bit, the fp32 GEMM followed by the stand-alone
+    LayerNorm(+add) kernel (the same values reach the same summation order), and both track the fp64 formula."""
+    L, W = amd._lib, amd.weights
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g)).to(DEV, dtype)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    wm = W.conv_matrix(w.view(N, K, 1, 1), dtype, DEV)
+    bias, ga, be = (torch.randn(N, generator=g).to(DEV) for _ in range(3))
+    res = torch.randn(M, N, generator=g).to(DEV)
+    assert L.lib.mic_conv2d_ln_supported(N) == 1
+    # two launches
+    u = torch.empty(M, N, device=DEV)
+    d = _linear_desc(L, x, wm, bias, u, N)
+    L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()))
+    y2, t2 = res.clone(), torch.empty(M, N, device=DEV, dtype=dtype)
+    if residual:
+        L.check(L.lib.mic_layernorm_add(u.data_ptr(), ga.data_ptr(), be.data_ptr(), y2.data_ptr(), y2.data_ptr(), t2.data_ptr(),
+                                        N, L.dtype_code(dtype), M, N, L.stream_ptr()))
+    else:
+        L.check(L.lib.mic_layernorm(u.data_ptr(), ga.data_ptr(), be.data_ptr(), y2.data_ptr(), t2.data_ptr(),
+                                    N, L.dtype_code(dtype), M, N, L.stream_ptr()))
+    # one launch, the residual stream updated in place
+    y1, t1 = res.clone(), torch.full((M, N), 7.0, device=DEV, dtype=dtype)
+    d = _linear_desc(L, x, wm, bias, y1, N)
+    d.res = y1.data_ptr() if residual else None
+    d.ln_gamma, d.ln_beta, d.ln_out, d.ld_ln_out = ga.data_ptr(), be.data_ptr(), t1.data_ptr(), N
+    L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(t1, t2)
+    ref = torch.nn.functional.layer_norm(x.double().cpu() @ wm[:N].double().cpu().T + bias.double().cpu(), (N,), ga.double().cpu(), be.double().cpu(), 1e-5)
+    if residual:
+        ref = ref + res.double().cpu()
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(y1.cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
+
+
+def test_linear_layernorm_epilogue_rejects_bad_arguments(amd):
+    L = amd._lib
+    x, wm, b = torch.zeros(64, 64, device=DEV), torch.zeros(512, 64, device=DEV), torch.zeros(512, device=DEV)
+    out, outb = torch.zeros(64, 512, device=DEV), torch.zeros(64, 512, device=DEV, dtype=torch.bfloat16)
+    assert L.lib.mic_conv2d_ln_supported(768) == 0 and L.lib.mic_conv2d_ln_supported(98) == 0
+    d = _linear_desc(L, x, wm, b, out, 512)
+    d.ln_gamma = d.ln_beta = b.data_ptr()
+    assert L.lib.mic_conv2d(C.byref(d), L.stream_ptr()) == -1 and b"LayerNorm epilogue" in L.lib.mic_last_error()   # N too wide
+    d = _linear_desc(L, x, wm, b, outb, 128)
+    d.out_dtype = L.BF16
+    d.ln_gamma = d.ln_beta = b.data_ptr()
+    assert L.lib.mic_conv2d(C.byref(d), L.stream_ptr()) == -1                                   # fp32 output only
+    d = _linear_desc(L, x, wm, b, out, 128)
+    d.ln_gamma = b.data_ptr()
+    assert L.lib.mic_conv2d(C.byref(d), L.stream_ptr()) == -1                                   # beta missing
+    d.ln_beta, d.relu = b.data_ptr(), 1
+    assert L.lib.mic_conv2d(C.byref(d), L.stream_ptr()) == -1                                   # no activation before the norm
+    torch.cuda.synchronize()
+
+
+def test_swin_forward_same_features_with_and_without_the_epilogue(amd):
+    """The encoder's features do not depend on whether LayerNorm rides in the GEMM epilogue (checked in a child process with
+    the fusion switched off by its environment knob)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import torch, image_captioning_amd as m\n"
+            "sd = m.weights.random_swin_state(3, embed=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8))\n"
+            "sd.update(m.weights.random_head_state('swin', 64, 1, in_dim=256))\n"
+            "enc = m.encoders.SwinV2Encoder(sd, torch.bfloat16, 'cuda:0')\n"
+            "img = torch.randn(3, 3, 96, 64, generator=torch.Generator().manual_seed(4))\n"
+            "f = enc(img)\n"
+            "print('SUM', f.float().double().sum().item(), f.float().abs().double().sum().item())\n")
+    outs = []
+    for knob in ("0", "1"):
+        env = dict(os.environ, MIC_SWIN_NO_LN_FUSE=knob)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("SUM")][0])
+    assert outs[0] == outs[1]
