@@ -552,6 +552,9 @@ int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int
  * attn) is the caller's memory as in mic_tr_step.  The call allocates nothing; the first call on a device
  * looks the array's address up.  The temporaries take, each rounded up to 256 bytes,
  *     N*H*(4 + e + 4 + 12 + e + 2e) + 2 * N*ceil(H/128)*8 bytes   (e = element size of dec->dtype),
+ * or, when the decoder carries the folded self-attention matrices and the fused attention launch applies (the
+ * fields qkvf and vfcache of `io` must then be usable as for mic_tr_step; qkvf is replaced by a slice as well),
+ *     N*H*(4 + e + 4 + 4*(2 + heads) + 2e) + 2 * N*ceil(H/128)*8 bytes,
  * and a call that needs more than MIC_STATIC_SCRATCH_BYTES is rejected with MIC_ERR_ARG (512 rows of hidden
  * size 512 in bf16 fit).  All calls on one GPU share that GPU's array, whatever their stream: calls that
  * overlap in time on one GPU race.  Nothing in the array has to start at zero (each temporary is written by the

@@ -137,7 +137,9 @@ def test_transformer_teacher_forced_logits_fp32(amd, golden_transformer, S):
 
 def test_transformer_bf16_tracks_fp32(amd, golden_transformer):
     """bf16 weights / GEMM inputs: greedy tokens may legitimately differ where two logits are closer
-    than bf16 resolution, so the check is on the summed log-prob (5% relative) and on agreement rate."""
+    than bf16 resolution, so the check is on the summed log-prob and on the agreement rate.  Measured on the
+    MI355X: every token of the four golden captions agrees and the beam scores differ by 2e-4 relative; the
+    bounds leave room for a few near-tie flips (10 % of the tokens) and 25x the score error."""
     from oracle import captioner_oracle as O
     g = golden_transformer
     model = _tr_model(amd, g, "plain", torch.bfloat16)
@@ -145,9 +147,9 @@ def test_transformer_bf16_tracks_fp32(amd, golden_transformer):
     caps, lp = model.generate_from_features(feats, model.vocab, 12, None, 1)
     ref = _rows(g["gen/plain/S49/T12/greedy/tokens"])
     agree = np.mean([a == b for r, c in zip(ref, caps) for a, b in zip(r, c)])
-    assert agree >= 0.5, f"bf16 greedy agreement {agree:.2f}"
+    assert agree >= 0.9, f"bf16 greedy agreement {agree:.2f}"
     caps, lp = model.generate_from_features(feats, model.vocab, 12, None, 3)
-    np.testing.assert_allclose(lp.cpu().numpy(), g["gen/plain/S49/T12/beam3/logp"], rtol=5e-2)
+    np.testing.assert_allclose(lp.cpu().numpy(), g["gen/plain/S49/T12/beam3/logp"], rtol=5e-3)
 
 
 def test_transformer_sampling_matches_oracle_on_shared_uniforms(amd, golden_transformer):

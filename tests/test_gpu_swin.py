@@ -135,6 +135,23 @@ def test_swin_s_configuration(amd):
     assert rel < 5e-2, f"bf16 Swin-S relative L2 error {rel:.4f}"
 
 
+def test_swin_t_depths_match_oracle(amd):
+    """Depths (2, 2, 6, 2) with 96 channels, the T configuration.  No reference counterpart: the reference builds swin_v2_s
+    only (models/encoders/swin.py:26); this pins the driver's handling of a different block count against the same oracle."""
+    from oracle import captioner_oracle as O
+    cfg = dict(depths=(2, 2, 6, 2))
+    sd = _sd(amd, 64, seed=5, **cfg)
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        ref = O.tokens_major(O.encoder_swin(sd, img))
+    got = amd.encoders.SwinV2Encoder(sd, torch.float32, DEV)(img).float().cpu()
+    assert got.shape == ref.shape == (2, 49, 64)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+    got16 = amd.encoders.SwinV2Encoder(sd, torch.bfloat16, DEV)(img).float().cpu()
+    rel = float((got16 - ref).norm() / ref.norm())
+    assert rel < 5e-2, f"bf16 Swin-T relative L2 error {rel:.4f}"
+
+
 def test_swin_tiny_bf16_tolerance(amd):
     from oracle import captioner_oracle as O
     sd = _sd(amd, 48, **TINY)
