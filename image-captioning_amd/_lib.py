@@ -48,6 +48,17 @@ class SkinnyDesc(C.Structure):
                 ("relu", i32)]
 
 
+GATHER_MAX = 16
+
+
+class BeamTailDesc(C.Structure):
+    _fields_ = [("logits", vp), ("ld", i32), ("V", i32), ("cur", vp), ("nxt", vp), ("parent", vp), ("live_images", vp), ("sqrt_tab", vp),
+                ("B", i32), ("K", i32), ("n_live_slots", i32), ("t", i32), ("t_cap", i32), ("eos_id", i32), ("finished_in_place", i32),
+                ("tok_emb", vp), ("pos_emb", vp), ("x", vp), ("xt", vp), ("ld_xt", i32), ("dtype", i32), ("H", i32), ("vocab", i32),
+                ("n_gather", i32), ("gather_src", vp * GATHER_MAX), ("gather_dst", vp * GATHER_MAX),
+                ("gather_row_bytes", i32 * GATHER_MAX), ("gather_stride_bytes", i32 * GATHER_MAX)]
+
+
 class AttnFusedDesc(C.Structure):
     _fields_ = [("qkvf", vp), ("kcache", vp), ("vfcache", vp), ("anc", vp), ("x", vp), ("x_ln", LnRef), ("self_b", vp), ("ln1_g", vp),
                 ("ln1_b", vp), ("kf", vp), ("vf", vp), ("c", vp), ("bo", vp), ("y", vp), ("stats_out", vp), ("attn_out", vp),
@@ -171,8 +182,12 @@ SIGNATURES = {
     "mic_beam_tail_supported": (C.c_int, [C.c_int, C.c_int]),
     "mic_beam_tail": (C.c_int, [vp, C.c_int, C.c_int, P(BeamState), P(BeamState), vp, vp, vp] + [C.c_int] * 6 + [vp, vp, vp, vp]
                       + [C.c_int] * 3 + [vp]),
+    "mic_beam_tail_ex": (C.c_int, [P(BeamTailDesc), vp]),
     "mic_lstm_cell": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_lstm_cell_ln_supported": (C.c_int, [C.c_int]),
+    "mic_lstm_cell_ln": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_gather_rows": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "mic_gather_rows_multi": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_int, vp]),
     "mic_logsoftmax_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, vp, vp, vp, vp]),
     "mic_sample_multinomial": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
     "mic_beam_select": (C.c_int, [P(BeamState), P(BeamState), vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -985,8 +985,85 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, float* __restr
     if (ht1) ht1[(long long)n * ld1 + j] = from_f32<T>(hn);
 }
 
+// The cell of the top layer with the LayerNorm that follows it (models/intermediate.py:63,65): one wave per row, 4 rows
+// per block, the row's h' kept in registers between the two.  Column order and arithmetic of the normalisation are those
+// of layernorm_kernel.  NV = float4 per lane (Hd <= 256 * NV).
+template <typename T, int NV>
+__global__ void lstm_cell_ln_kernel(const float* __restrict__ gates, float* __restrict__ c, float* __restrict__ h, T* ht0, int ld0,
+                                    const float* __restrict__ lg, const float* __restrict__ lb, float* hn, T* hnt, int ld_hnt, int N,
+                                    int Hd) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* g = gates + (long long)row * 4 * Hd;
+    float4 hv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = lane * 4 + 256 * k;
+        hv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < Hd) {
+            const float4 gi = *reinterpret_cast<const float4*>(g + j), gf = *reinterpret_cast<const float4*>(g + Hd + j);
+            const float4 gc = *reinterpret_cast<const float4*>(g + 2 * Hd + j), go = *reinterpret_cast<const float4*>(g + 3 * Hd + j);
+            float4 cv = *reinterpret_cast<const float4*>(c + (long long)row * Hd + j);
+            cv.x = sigmoidf_(gf.x) * cv.x + sigmoidf_(gi.x) * tanhf(gc.x);
+            cv.y = sigmoidf_(gf.y) * cv.y + sigmoidf_(gi.y) * tanhf(gc.y);
+            cv.z = sigmoidf_(gf.z) * cv.z + sigmoidf_(gi.z) * tanhf(gc.z);
+            cv.w = sigmoidf_(gf.w) * cv.w + sigmoidf_(gi.w) * tanhf(gc.w);
+            hv[k] = make_float4(sigmoidf_(go.x) * tanhf(cv.x), sigmoidf_(go.y) * tanhf(cv.y), sigmoidf_(go.z) * tanhf(cv.z),
+                                sigmoidf_(go.w) * tanhf(cv.w));
+            *reinterpret_cast<float4*>(c + (long long)row * Hd + j) = cv;
+            *reinterpret_cast<float4*>(h + (long long)row * Hd + j) = hv[k];
+            if (ht0) {
+                T* t = ht0 + (long long)row * ld0 + j;
+                t[0] = from_f32<T>(hv[k].x); t[1] = from_f32<T>(hv[k].y); t[2] = from_f32<T>(hv[k].z); t[3] = from_f32<T>(hv[k].w);
+            }
+            s += ln_sum4(hv[k].x, hv[k].y, hv[k].z, hv[k].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)Hd;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (lane * 4 + 256 * k < Hd) q += ln_sq4(hv[k].x, hv[k].y, hv[k].z, hv[k].w, mean);
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)Hd + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = lane * 4 + 256 * k;
+        if (j >= Hd) continue;
+        const float4 gg = *reinterpret_cast<const float4*>(lg + j), bb = *reinterpret_cast<const float4*>(lb + j);
+        float4 o;
+        o.x = ln_apply(hv[k].x, mean, rstd, gg.x, bb.x);
+        o.y = ln_apply(hv[k].y, mean, rstd, gg.y, bb.y);
+        o.z = ln_apply(hv[k].z, mean, rstd, gg.z, bb.z);
+        o.w = ln_apply(hv[k].w, mean, rstd, gg.w, bb.w);
+        if (hn) *reinterpret_cast<float4*>(hn + (long long)row * Hd + j) = o;
+        if (hnt) {
+            T* t = hnt + (long long)row * ld_hnt + j;
+            t[0] = from_f32<T>(o.x); t[1] = from_f32<T>(o.y); t[2] = from_f32<T>(o.z); t[3] = from_f32<T>(o.w);
+        }
+    }
+}
+
 __global__ void gather_rows_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const int32_t* __restrict__ idx,
                                    int rows, int words) {
+    const long long total = (long long)rows * words;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / words), w = (int)(i - (long long)r * words);
+        dst[i] = src[(long long)idx[r] * words + w];
+    }
+}
+
+struct GatherMulti {
+    const uint32_t* src[MIC_GATHER_MAX];
+    uint32_t* dst[MIC_GATHER_MAX];
+    int words[MIC_GATHER_MAX];
+};
+
+// blockIdx.y names the buffer: one launch moves the survivors' rows of every buffer
+__global__ void gather_rows_multi_kernel(const GatherMulti g, const int32_t* __restrict__ idx, int rows) {
+    const uint32_t* __restrict__ src = g.src[blockIdx.y];
+    uint32_t* __restrict__ dst = g.dst[blockIdx.y];
+    const int words = g.words[blockIdx.y];
     const long long total = (long long)rows * words;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / words), w = (int)(i - (long long)r * words);
@@ -1146,6 +1223,28 @@ extern "C" int mic_lstm_cell(const float* gates, float* c, float* h, void* ht0, 
     return 0;
 }
 
+extern "C" int mic_lstm_cell_ln_supported(int Hd) { return Hd > 0 && Hd % 4 == 0 && Hd <= 1024; }
+
+extern "C" int mic_lstm_cell_ln(const float* gates, float* c, float* h, void* ht0, int ld0, const float* ln_g, const float* ln_b, float* hn,
+                                void* hnt, int ld_hnt, int dtype, int N, int Hd, void* stream) {
+    MIC_ARG_CHECK(gates && c && h && ln_g && ln_b && (hn || hnt) && N > 0, "mic_lstm_cell_ln: bad arguments");
+    MIC_ARG_CHECK(mic_lstm_cell_ln_supported(Hd), "mic_lstm_cell_ln: Hd=%d must be a multiple of 4, at most 1024", Hd);
+    MIC_ARG_CHECK(dtype == MIC_F32 || dtype == MIC_BF16, "mic_lstm_cell_ln: bad dtype %d", dtype);
+    MIC_ARG_CHECK((((uintptr_t)gates | (uintptr_t)c | (uintptr_t)h | (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)hn) & 15) == 0,
+                  "mic_lstm_cell_ln: fp32 pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((N + 3) / 4), block(256);
+#define MIC_CELL_LN(TT, NV) MIC_LAUNCH((lstm_cell_ln_kernel<TT, NV>), grid, block, 0, s, gates, c, h, (TT*)ht0, ld0, ln_g, ln_b, hn, (TT*)hnt, ld_hnt, N, Hd)
+    const int nv = (Hd + 255) / 256;
+    if (dtype == MIC_BF16) {
+        if (nv == 1) MIC_CELL_LN(bf16_t, 1); else if (nv == 2) MIC_CELL_LN(bf16_t, 2); else MIC_CELL_LN(bf16_t, 4);
+    } else {
+        if (nv == 1) MIC_CELL_LN(float, 1); else if (nv == 2) MIC_CELL_LN(float, 2); else MIC_CELL_LN(float, 4);
+    }
+#undef MIC_CELL_LN
+    return 0;
+}
+
 extern "C" int mic_gather_rows(const void* src, void* dst, const int32_t* idx, int rows, int row_bytes, void* stream) {
     MIC_ARG_CHECK(src && dst && idx && rows > 0 && row_bytes > 0 && row_bytes % 4 == 0, "mic_gather_rows: bad arguments");
     MIC_ARG_CHECK(src != dst, "mic_gather_rows: in-place gather is not supported");
@@ -1153,5 +1252,24 @@ extern "C" int mic_gather_rows(const void* src, void* dst, const int32_t* idx, i
     long long g = (total + 255) / 256;
     if (g > 4096) g = 4096;
     MIC_LAUNCH(gather_rows_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, (uint32_t*)dst, idx, rows, row_bytes / 4);
+    return 0;
+}
+
+extern "C" int mic_gather_rows_multi(const void* const* src, void* const* dst, const int32_t* row_bytes, int n_bufs, const int32_t* idx,
+                                     int rows, void* stream) {
+    MIC_ARG_CHECK(src && dst && row_bytes && idx && rows > 0, "mic_gather_rows_multi: bad arguments");
+    MIC_ARG_CHECK(n_bufs >= 1 && n_bufs <= MIC_GATHER_MAX, "mic_gather_rows_multi: %d buffers (1..%d)", n_bufs, MIC_GATHER_MAX);
+    GatherMulti g{};
+    long long most = 0;
+    for (int i = 0; i < n_bufs; ++i) {
+        MIC_ARG_CHECK(src[i] && dst[i] && src[i] != dst[i] && row_bytes[i] > 0 && row_bytes[i] % 4 == 0,
+                      "mic_gather_rows_multi: buffer %d: null, in-place or row size %d not a multiple of 4", i, row_bytes[i]);
+        g.src[i] = (const uint32_t*)src[i]; g.dst[i] = (uint32_t*)dst[i]; g.words[i] = row_bytes[i] / 4;
+        const long long total = (long long)rows * g.words[i];
+        most = total > most ? total : most;
+    }
+    long long gx = (most + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    MIC_LAUNCH(gather_rows_multi_kernel, dim3((unsigned)gx, (unsigned)n_bufs), dim3(256), 0, (hipStream_t)stream, g, idx, rows);
     return 0;
 }

@@ -653,9 +653,11 @@ extern "C" int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_works
 // ---------------------------------------------------------------------------------------------
 // LSTM decoders
 // ---------------------------------------------------------------------------------------------
-extern "C" int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, const int32_t* tokens, int ld_tok, int pos,
-                             const void* feat_t, int ld_feat, void* stream) {
-    MIC_ARG_CHECK(dec && ws && (tokens || feat_t), "mic_lstm_step: null pointer");
+namespace {
+// skip_embed: the input half of xh[0] already holds the embedding of this step's tokens (written by the previous step's tail)
+int lstm_step_impl(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, const int32_t* tokens, int ld_tok, int pos,
+                   const void* feat_t, int ld_feat, bool skip_embed, void* stream) {
+    MIC_ARG_CHECK(dec && ws && (tokens || feat_t || skip_embed), "mic_lstm_step: null pointer");
     MIC_ARG_CHECK(dec->dtype == MIC_F32 || dec->dtype == MIC_BF16, "mic_lstm_step: bad dtype");
     MIC_ARG_CHECK(dec->layers >= 1 && dec->layers <= MIC_MAX_LAYERS && dec->E > 0 && dec->Hd > 0 && ws->N > 0, "mic_lstm_step: bad sizes");
     MIC_ARG_CHECK(dec->E % 4 == 0 && dec->Hd % 4 == 0, "mic_lstm_step: E=%d and Hd=%d must be multiples of 4", dec->E, dec->Hd);
@@ -665,9 +667,11 @@ extern "C" int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspa
     if (feat_t) {
         MIC_HIP_CHECK(hipMemcpy2DAsync(ws->xh[0], (size_t)dec->kpad[0] * sz, feat_t, (size_t)ld_feat * sz, (size_t)E * sz, N,
                                        hipMemcpyDeviceToDevice, s));
-    } else {
+    } else if (!skip_embed) {
         MIC_TRY(mic_embed_pos(tokens, ld_tok, pos, dec->embed, nullptr, nullptr, ws->xh[0], dec->kpad[0], dt, N, E, dec->vocab, s));
     }
+    static const bool no_cell_ln = getenv("MIC_NO_CELL_LN") != nullptr;  // comparison runs: LayerNorm as its own launch
+    bool ln_done = false;
     for (int l = 0; l < L; ++l) {
         const int in_dim = l == 0 ? E : Hd;
         MIC_TRY(proj(dt, dec->wf[l], ws->xh[l], dec->kpad[l], N, dec->kpad[l], dec->w[l], dec->b[l], ws->gates, MIC_F32, 4 * Hd, 4 * Hd, 0, s));
@@ -675,11 +679,25 @@ extern "C" int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspa
         int ld_up = 0;
         if (l + 1 < L) { up = ws->xh[l + 1]; ld_up = dec->kpad[l + 1]; }
         else if (dec->kind == 0) { up = ws->hnt; ld_up = dec->out_k; }
-        MIC_TRY(mic_lstm_cell(ws->gates, ws->c[l], ws->h[l], (char*)ws->xh[l] + (size_t)in_dim * sz, dec->kpad[l], up, ld_up, dt, N, Hd, s));
+        void* own = (char*)ws->xh[l] + (size_t)in_dim * sz;
+        if (l + 1 == L && dec->kind == 1 && !no_cell_ln && mic_lstm_cell_ln_supported(Hd)) {
+            MIC_TRY(mic_lstm_cell_ln(ws->gates, ws->c[l], ws->h[l], own, dec->kpad[l], dec->ln_g, dec->ln_b, ws->hn, ws->hnt, dec->out_k, dt, N,
+                                     Hd, s));
+            ln_done = true;
+        } else {
+            MIC_TRY(mic_lstm_cell(ws->gates, ws->c[l], ws->h[l], own, dec->kpad[l], up, ld_up, dt, N, Hd, s));
+        }
     }
-    if (dec->kind == 1)
+    if (dec->kind == 1 && !ln_done)
         MIC_TRY(mic_layernorm(ws->h[L - 1], dec->ln_g, dec->ln_b, ws->hn, ws->hnt, dec->out_k, dt, N, Hd, s));
     return proj(dt, dec->out_wf, ws->hnt, dec->out_k, N, dec->out_k, dec->out_w, dec->out_b, ws->logits, MIC_F32, dec->vocab, dec->vocab, 0, s);
+}
+}  // namespace
+
+extern "C" int mic_lstm_step(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, const int32_t* tokens, int ld_tok, int pos,
+                             const void* feat_t, int ld_feat, void* stream) {
+    MIC_ARG_CHECK(dec && ws && (tokens || feat_t), "mic_lstm_step: null pointer");
+    return lstm_step_impl(dec, ws, tokens, ld_tok, pos, feat_t, ld_feat, false, stream);
 }
 
 namespace {
@@ -702,22 +720,50 @@ extern "C" int mic_lstm_beam_steps(const mic_lstm_decoder* dec, const mic_lstm_w
     MIC_ARG_CHECK(dec->layers >= 1 && dec->layers <= MIC_MAX_LAYERS, "mic_lstm_beam_steps: bad layer count %d", dec->layers);
     const int N = B * K;
     const int sz = (int)mic_dtype_size(dec->dtype);
+    static const bool no_tail = getenv("MIC_NO_BEAM_TAIL") != nullptr;
+    // one launch for top-k, selection, the survivors' state and the next embedding: the recurrent halves of every layer's
+    // [x | h] matrix and the cell states are all that must travel (the input halves are rewritten before they are read)
+    const bool tail = !no_tail && mic_beam_tail_supported(K, dec->vocab) && 2 * dec->layers <= MIC_GATHER_MAX && dec->E % 4 == 0;
     auto body = [&](void* stream) -> int {
         for (int t = t0; t < t1; ++t) {
             const mic_lstm_workspace* wc = &ws[t & 1];
             const mic_lstm_workspace* wn = &ws[(t + 1) & 1];
             const mic_beam_state* cur = &st[t & 1];
             const mic_beam_state* nxt = &st[(t + 1) & 1];
-            MIC_TRY(mic_lstm_step(dec, wc, cur->seq, t_cap, t, nullptr, 0, stream));
+            MIC_TRY(lstm_step_impl(dec, wc, cur->seq, t_cap, t, nullptr, 0, tail && t > t0, stream));
+            if (tail) {
+                mic_beam_tail_desc d{};
+                d.logits = wc->logits; d.ld = dec->vocab; d.V = dec->vocab; d.cur = cur; d.nxt = nxt; d.parent = parent;
+                d.live_images = live_images + t; d.sqrt_tab = sqrt_tab;
+                d.B = B; d.K = K; d.n_live_slots = t == 0 ? 1 : K; d.t = t; d.t_cap = t_cap; d.eos_id = eos_id; d.finished_in_place = 1;
+                if (t + 1 < t1) {
+                    d.tok_emb = dec->embed; d.xt = wn->xh[0]; d.ld_xt = dec->kpad[0]; d.dtype = dec->dtype; d.H = dec->E; d.vocab = dec->vocab;
+                }
+                for (int l = 0; l < dec->layers; ++l) {
+                    const int in_dim = l == 0 ? dec->E : dec->Hd;
+                    d.gather_src[2 * l] = wc->c[l]; d.gather_dst[2 * l] = wn->c[l];
+                    d.gather_row_bytes[2 * l] = d.gather_stride_bytes[2 * l] = dec->Hd * 4;
+                    d.gather_src[2 * l + 1] = (const char*)wc->xh[l] + (size_t)in_dim * sz;
+                    d.gather_dst[2 * l + 1] = (char*)wn->xh[l] + (size_t)in_dim * sz;
+                    d.gather_row_bytes[2 * l + 1] = dec->Hd * sz; d.gather_stride_bytes[2 * l + 1] = dec->kpad[l] * sz;
+                }
+                d.n_gather = 2 * dec->layers;
+                MIC_TRY(mic_beam_tail_ex(&d, stream));
+                continue;
+            }
             MIC_TRY(mic_logsoftmax_topk(wc->logits, dec->vocab, N, dec->vocab, K, 1.0f, 0, top_val, top_idx, nullptr, stream));
             MIC_TRY(mic_beam_select(cur, nxt, top_val, top_idx, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t, t_cap,
                                     eos_id, 1, stream));
+            // the fp32 h of a layer is rewritten by the next step's cell before anything reads it: only the cell
+            // state and the GEMM input [x | h] travel with the survivors, all layers in one launch
+            const void* src[2 * MIC_MAX_LAYERS];
+            void* dst[2 * MIC_MAX_LAYERS];
+            int32_t bytes[2 * MIC_MAX_LAYERS];
             for (int l = 0; l < dec->layers; ++l) {
-                // the fp32 h of a layer is rewritten by the next step's cell before anything reads it: only the cell
-                // state and the GEMM input [x | h] travel with the survivors
-                MIC_TRY(mic_gather_rows(wc->c[l], wn->c[l], parent, N, dec->Hd * 4, stream));
-                MIC_TRY(mic_gather_rows(wc->xh[l], wn->xh[l], parent, N, dec->kpad[l] * sz, stream));
+                src[2 * l] = wc->c[l]; dst[2 * l] = wn->c[l]; bytes[2 * l] = dec->Hd * 4;
+                src[2 * l + 1] = wc->xh[l]; dst[2 * l + 1] = wn->xh[l]; bytes[2 * l + 1] = dec->kpad[l] * sz;
             }
+            MIC_TRY(mic_gather_rows_multi(src, dst, bytes, 2 * dec->layers, parent, N, stream));
         }
         return 0;
     };

@@ -391,7 +391,12 @@ struct TailArgs {
     const float *tok_emb, *pos_emb;  // embedding for position b.t + 1 is skipped when tok_emb is null
     float* x;
     void* xt;
-    int H, vocab, xt_bf16;
+    int H, vocab, xt_bf16, ld_xt;
+    // per-beam state that travels with the survivors: dst[g][row r of the image] = src[g][parent of r], n_gather buffers
+    int n_gather;
+    const uint32_t* g_src[MIC_GATHER_MAX];
+    uint32_t* g_dst[MIC_GATHER_MAX];
+    int g_words[MIC_GATHER_MAX], g_stride[MIC_GATHER_MAX];  // 4-byte words per row to move / between rows
 };
 
 // GW threads work on one row of logits (256, or 128 for more than four beams so that every row of the image has a
@@ -494,8 +499,18 @@ __global__ __launch_bounds__(GW * (K < 1024 / GW ? K : 1024 / GW)) void beam_tai
     }
     if (tid < a.b.n_live_slots) slot_store(a.b, sh, tid, slot);
     beam_select_body(a.b, img, lane, tid < 64, sh, tv, ti, new_tok);
-    if (!a.tok_emb) return;
+    if (!a.tok_emb && a.n_gather == 0) return;
     __syncthreads();
+    // survivors' state rows: slot r of the next step continues slot c_slot[win[r]] of this one
+    for (int g = 0; g < a.n_gather; ++g) {
+        const int words = a.g_words[g];
+        for (int i = tid; i < K * words; i += GW * G) {
+            const int r = i / words, w = i - r * words;
+            const long long src_row = (long long)img * K + sh.c_slot[sh.win[r]], dst_row = (long long)img * K + r;
+            a.g_dst[g][dst_row * a.g_stride[g] + w] = a.g_src[g][src_row * a.g_stride[g] + w];
+        }
+    }
+    if (!a.tok_emb) return;
     const int hv = a.H >> 2, pos = a.b.t + 1;
     for (int i = tid; i < K * hv; i += GW * G) {
         const int r = i / hv, c = (i - r * hv) << 2;
@@ -503,16 +518,18 @@ __global__ __launch_bounds__(GW * (K < 1024 / GW ? K : 1024 / GW)) void beam_tai
         id = id < 0 ? a.b.eos_id : id;  // a finished beam's row is never looked at again: any valid token serves
         id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
         float4 v = *reinterpret_cast<const float4*>(a.tok_emb + (long long)id * a.H + c);
-        const float4 p = *reinterpret_cast<const float4*>(a.pos_emb + (long long)pos * a.H + c);
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        if (a.pos_emb) {
+            const float4 p = *reinterpret_cast<const float4*>(a.pos_emb + (long long)pos * a.H + c);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
         const long long n = (long long)img * K + r;
         if (a.x) *reinterpret_cast<float4*>(a.x + n * a.H + c) = v;
         if (a.xt) {
             if (a.xt_bf16) {
-                bf16_t* o = (bf16_t*)a.xt + n * a.H + c;
+                bf16_t* o = (bf16_t*)a.xt + n * a.ld_xt + c;
                 o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
             } else {
-                *reinterpret_cast<float4*>((float*)a.xt + n * a.H + c) = v;
+                *reinterpret_cast<float4*>((float*)a.xt + n * a.ld_xt + c) = v;
             }
         }
     }
@@ -613,22 +630,35 @@ extern "C" int mic_beam_select(const mic_beam_state* cur, const mic_beam_state* 
 
 extern "C" int mic_beam_tail_supported(int K, int V) { return K >= 1 && K <= KMAX && V >= 1 && V <= 256 * 16; }
 
-extern "C" int mic_beam_tail(const float* logits, int ld, int V, const mic_beam_state* cur, const mic_beam_state* nxt, int32_t* parent,
-                             int32_t* live_images, const double* sqrt_tab, int B, int K, int n_live_slots, int t, int t_cap, int eos_id,
-                             const float* tok_emb, const float* pos_emb, float* x, void* xt, int dtype, int H, int vocab, void* stream) {
-    MIC_ARG_CHECK(logits && cur && nxt && parent && sqrt_tab, "mic_beam_tail: null pointer");
+extern "C" int mic_beam_tail_ex(const mic_beam_tail_desc* d, void* stream) {
+    MIC_ARG_CHECK(d && d->logits && d->cur && d->nxt && d->parent && d->sqrt_tab, "mic_beam_tail: null pointer");
+    const mic_beam_state *cur = d->cur, *nxt = d->nxt;
+    const int B = d->B, K = d->K, V = d->V;
     MIC_ARG_CHECK(cur->score && cur->len && cur->seq && nxt->score && nxt->len && nxt->seq, "mic_beam_tail: null state");
     MIC_ARG_CHECK((cur->anc == nullptr) == (nxt->anc == nullptr), "mic_beam_tail: anc must be set in both states or neither");
-    MIC_ARG_CHECK(B > 0 && mic_beam_tail_supported(K, V) && ld >= V, "mic_beam_tail: B=%d K=%d V=%d ld=%d (K <= %d, V <= 4096)", B, K, V, ld, KMAX);
-    MIC_ARG_CHECK(n_live_slots >= 1 && n_live_slots <= K, "mic_beam_tail: n_live_slots=%d", n_live_slots);
-    MIC_ARG_CHECK(t >= 0 && t + 2 <= t_cap, "mic_beam_tail: step %d does not fit t_cap=%d", t, t_cap);
-    MIC_ARG_CHECK(!tok_emb || (pos_emb && (x || xt) && H > 0 && H % 4 == 0 && vocab > 0 && (dtype == MIC_F32 || dtype == MIC_BF16)),
-                  "mic_beam_tail: the embedding of the next position needs pos_emb, an output and H %% 4 == 0");
+    MIC_ARG_CHECK(B > 0 && mic_beam_tail_supported(K, V) && d->ld >= V, "mic_beam_tail: B=%d K=%d V=%d ld=%d (K <= %d, V <= 4096)", B, K, V, d->ld, KMAX);
+    MIC_ARG_CHECK(d->n_live_slots >= 1 && d->n_live_slots <= K, "mic_beam_tail: n_live_slots=%d", d->n_live_slots);
+    MIC_ARG_CHECK(d->t >= 0 && d->t + 2 <= d->t_cap, "mic_beam_tail: step %d does not fit t_cap=%d", d->t, d->t_cap);
+    MIC_ARG_CHECK(!d->tok_emb || ((d->x || d->xt) && d->H > 0 && d->H % 4 == 0 && d->vocab > 0 && (d->dtype == MIC_F32 || d->dtype == MIC_BF16) &&
+                                  (!d->xt || (d->ld_xt >= d->H && d->ld_xt % 4 == 0))),
+                  "mic_beam_tail: the embedding of the next position needs an output, H %% 4 == 0 and ld_xt >= H");
+    MIC_ARG_CHECK(d->n_gather >= 0 && d->n_gather <= MIC_GATHER_MAX, "mic_beam_tail: %d gathered buffers (max %d)", d->n_gather, MIC_GATHER_MAX);
     TailArgs a{};
-    a.b.cur = *cur; a.b.nxt = *nxt; a.b.parent = parent; a.b.live_images = live_images; a.b.sqrt_tab = sqrt_tab;
-    a.b.B = B; a.b.K = K; a.b.n_live_slots = n_live_slots; a.b.t = t; a.b.t_cap = t_cap; a.b.eos_id = eos_id; a.b.in_place = 0;
-    a.logits = logits; a.ld = ld; a.V = V; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x = x; a.xt = xt; a.H = H; a.vocab = vocab;
-    a.xt_bf16 = dtype == MIC_BF16;
+    a.b.cur = *cur; a.b.nxt = *nxt; a.b.parent = d->parent; a.b.live_images = d->live_images; a.b.sqrt_tab = d->sqrt_tab;
+    a.b.B = B; a.b.K = K; a.b.n_live_slots = d->n_live_slots; a.b.t = d->t; a.b.t_cap = d->t_cap; a.b.eos_id = d->eos_id;
+    a.b.in_place = d->finished_in_place;
+    a.logits = d->logits; a.ld = d->ld; a.V = V; a.tok_emb = d->tok_emb; a.pos_emb = d->pos_emb; a.x = d->x; a.xt = d->xt; a.H = d->H;
+    a.vocab = d->vocab; a.ld_xt = d->ld_xt;
+    a.xt_bf16 = d->dtype == MIC_BF16;
+    a.n_gather = d->n_gather;
+    for (int g = 0; g < d->n_gather; ++g) {
+        MIC_ARG_CHECK(d->gather_src[g] && d->gather_dst[g] && d->gather_src[g] != d->gather_dst[g] && d->gather_row_bytes[g] > 0 &&
+                          d->gather_row_bytes[g] % 4 == 0 && d->gather_stride_bytes[g] % 4 == 0 && d->gather_stride_bytes[g] >= d->gather_row_bytes[g] &&
+                          (((uintptr_t)d->gather_src[g] | (uintptr_t)d->gather_dst[g]) & 3) == 0,
+                      "mic_beam_tail: gathered buffer %d: null, in place, or sizes not multiples of 4 bytes", g);
+        a.g_src[g] = (const uint32_t*)d->gather_src[g]; a.g_dst[g] = (uint32_t*)d->gather_dst[g];
+        a.g_words[g] = d->gather_row_bytes[g] / 4; a.g_stride[g] = d->gather_stride_bytes[g] / 4;
+    }
     hipStream_t s = (hipStream_t)stream;
 #define MIC_TAIL_CASE(KK) \
     case KK: MIC_LAUNCH((beam_tail_kernel<KK, (KK <= 4 ? 256 : 128)>), dim3(B), dim3(KK <= 4 ? 256 * KK : 128 * KK), 0, s, a); break;
@@ -638,6 +668,17 @@ extern "C" int mic_beam_tail(const float* logits, int ld, int V, const mic_beam_
     }
 #undef MIC_TAIL_CASE
     return 0;
+}
+
+extern "C" int mic_beam_tail(const float* logits, int ld, int V, const mic_beam_state* cur, const mic_beam_state* nxt, int32_t* parent,
+                             int32_t* live_images, const double* sqrt_tab, int B, int K, int n_live_slots, int t, int t_cap, int eos_id,
+                             const float* tok_emb, const float* pos_emb, float* x, void* xt, int dtype, int H, int vocab, void* stream) {
+    MIC_ARG_CHECK(!tok_emb || pos_emb, "mic_beam_tail: the embedding of the next position needs pos_emb");
+    mic_beam_tail_desc d{};
+    d.logits = logits; d.ld = ld; d.V = V; d.cur = cur; d.nxt = nxt; d.parent = parent; d.live_images = live_images; d.sqrt_tab = sqrt_tab;
+    d.B = B; d.K = K; d.n_live_slots = n_live_slots; d.t = t; d.t_cap = t_cap; d.eos_id = eos_id;
+    d.tok_emb = tok_emb; d.pos_emb = pos_emb; d.x = x; d.xt = xt; d.ld_xt = H; d.dtype = dtype; d.H = H; d.vocab = vocab;
+    return mic_beam_tail_ex(&d, stream);
 }
 
 extern "C" int mic_beam_finalize(const mic_beam_state* st, const double* sqrt_tab, int B, int K, int t_cap, int32_t* tokens,

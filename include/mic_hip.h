@@ -335,6 +335,16 @@ int mic_lstm_cell(const float* gates, float* c, float* h, void* ht0, int ld0, vo
 /* dst[r,:] = src[idx[r],:] for `rows` rows of `row_bytes` bytes (multiple of 4):
  * beam reorder of per-beam recurrent state (the list slicing at models/image_captioner.py:148-149). */
 int mic_gather_rows(const void* src, void* dst, const int32_t* idx, int rows, int row_bytes, void* stream);
+/* The same for up to MIC_GATHER_MAX buffers in one launch (every state tensor of every layer). */
+int mic_gather_rows_multi(const void* const* src, void* const* dst, const int32_t* row_bytes, int n_bufs, const int32_t* idx,
+                          int rows, void* stream);
+
+/* mic_lstm_cell of the top layer followed by the LayerNorm of the intermediate decoder (models/intermediate.py:63,65) in one
+ * launch: h' also goes to ht0 (the layer's own recurrent input), hn / hnt receive LayerNorm(h') in fp32 / `dtype`
+ * (either may be NULL).  Hd % 4 == 0, Hd <= 1024. */
+int mic_lstm_cell_ln_supported(int Hd);
+int mic_lstm_cell_ln(const float* gates, float* c, float* h, void* ht0, int ld0, const float* ln_g, const float* ln_b, float* hn,
+                     void* hnt, int ld_hnt, int dtype, int N, int Hd, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Search kernels
@@ -384,6 +394,34 @@ int mic_beam_tail_supported(int K, int V);
 int mic_beam_tail(const float* logits, int ld, int V, const mic_beam_state* cur, const mic_beam_state* nxt, int32_t* parent,
                   int32_t* live_images, const double* sqrt_tab, int B, int K, int n_live_slots, int t, int t_cap, int eos_id,
                   const float* tok_emb, const float* pos_emb, float* x, void* xt, int dtype, int H, int vocab, void* stream);
+
+/* The same launch in its general form: finished beams kept in place (finished_in_place = 1: the LSTM family's search,
+ * models/image_captioner.py:107-159), an embedding without positional table (pos_emb NULL) written with its own row stride
+ * (ld_xt elements of `dtype`: the input half of an LSTM layer's [x | h] matrix), and up to MIC_GATHER_MAX per-beam state
+ * buffers moved with the survivors, dst[b*K + r, :row_bytes] = src[parent of (b, r), :row_bytes] with rows stride_bytes apart
+ * (the list slicing at models/image_captioner.py:148-149).  With the gathers a beam-search step of the LSTM decoders ends in
+ * this one launch instead of top-k + selection + one gather per state tensor + the next step's embedding. */
+#define MIC_GATHER_MAX 16
+typedef struct mic_beam_tail_desc {
+    const float* logits;       /* [B*K][ld] fp32 */
+    int32_t ld, V;
+    const mic_beam_state* cur; /* state before the step */
+    const mic_beam_state* nxt; /* state after it */
+    int32_t* parent;           /* [B*K] out */
+    int32_t* live_images;      /* one counter, incremented per image with a live beam, or NULL */
+    const double* sqrt_tab;
+    int32_t B, K, n_live_slots, t, t_cap, eos_id, finished_in_place;
+    const float* tok_emb;      /* [vocab][H] fp32, NULL = no embedding */
+    const float* pos_emb;      /* [positions][H] fp32 or NULL */
+    float* x;                  /* [B*K][H] fp32 or NULL */
+    void* xt;                  /* [B*K][ld_xt] dtype or NULL */
+    int32_t ld_xt, dtype, H, vocab;
+    int32_t n_gather;
+    const void* gather_src[MIC_GATHER_MAX];
+    void* gather_dst[MIC_GATHER_MAX];
+    int32_t gather_row_bytes[MIC_GATHER_MAX], gather_stride_bytes[MIC_GATHER_MAX];
+} mic_beam_tail_desc;
+int mic_beam_tail_ex(const mic_beam_tail_desc* d, void* stream);
 
 /* Best beam per image (first maximum of score/sqrt(len), models/transformer.py:635-638):
  * tokens [B][t_cap] (-1 padded), lengths [B], score fp32 [B]; if attn_hist != NULL

@@ -40,10 +40,10 @@ def test_struct_layouts_match_the_header():
     #include <stddef.h>
     #include "mic_hip.h"
     int main(void) {
-      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mic_conv_desc), sizeof(mic_beam_state), sizeof(mic_conv_layer),
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mic_conv_desc), sizeof(mic_beam_state), sizeof(mic_conv_layer),
              sizeof(mic_resnet50), sizeof(mic_tr_layer), sizeof(mic_tr_decoder), sizeof(mic_tr_workspace),
              sizeof(mic_lstm_decoder), sizeof(mic_lstm_workspace), sizeof(mic_ln_ref), sizeof(mic_skinny_desc),
-             sizeof(mic_swin_block), sizeof(mic_swin_merge), sizeof(mic_swin), sizeof(mic_fused_tail), sizeof(mic_attn_fused_desc));
+             sizeof(mic_swin_block), sizeof(mic_swin_merge), sizeof(mic_swin), sizeof(mic_fused_tail), sizeof(mic_attn_fused_desc), sizeof(mic_beam_tail_desc));
       printf("%zu %zu %zu %zu\n", offsetof(mic_conv_desc, in_img_stride), offsetof(mic_conv_desc, k_valid),
              offsetof(mic_tr_decoder, out_w), offsetof(mic_lstm_decoder, out_k));
       return 0;
@@ -56,7 +56,7 @@ def test_struct_layouts_match_the_header():
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         sizes, offs = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().split("\n")
     got = [C.sizeof(x) for x in (L.ConvDesc, L.BeamState, L.ConvLayer, L.Resnet50, L.TrLayer, L.TrDecoder, L.TrWorkspace,
-                                 L.LstmDecoder, L.LstmWorkspace, L.LnRef, L.SkinnyDesc, L.SwinBlock, L.SwinMerge, L.Swin, L.FusedTail, L.AttnFusedDesc)]
+                                 L.LstmDecoder, L.LstmWorkspace, L.LnRef, L.SkinnyDesc, L.SwinBlock, L.SwinMerge, L.Swin, L.FusedTail, L.AttnFusedDesc, L.BeamTailDesc)]
     assert got == [int(v) for v in sizes.split()]
     assert [L.ConvDesc.in_img_stride.offset, L.ConvDesc.k_valid.offset, L.TrDecoder.out_w.offset, L.LstmDecoder.out_k.offset] == \
         [int(v) for v in offs.split()]

@@ -277,3 +277,110 @@ def test_fused_step_bf16_tracks_unfused(amd, monkeypatch):
     for b in range(B):
         for p in range(int(lens[b]) - 1):
             assert abs(float(a[b, p].sum()) - 1.0) < 1e-3
+
+
+@pytest.mark.parametrize("K,B,V,t,dtype", [(3, 6, 3500, 4, torch.bfloat16), (5, 4, 1000, 7, torch.float32), (1, 5, 300, 3, torch.bfloat16)])
+def test_beam_tail_in_place_with_state_gathers(amd, K, B, V, t, dtype):
+    """The general form of the tail as the LSTM search uses it: finished beams stay in their slots, the embedding has no
+    positional part and lands in the input half of a wider [x | h] matrix, and four per-beam state buffers (two with a row
+    stride larger than the bytes moved) follow the survivors.  Reference: top-k + in-place selection + mic_gather_rows per
+    buffer + mic_embed_pos."""
+    L = amd._lib
+    N, t_cap, E, Hd, eos = B * K, 16, 32, 48, 2
+    kpad = E + Hd + 16
+    g = torch.Generator().manual_seed(80 + K + t)
+    logits = (torch.randn(N, V, generator=g) * 3).to(DEV)
+    logits[:, eos] += 4.0
+    fin = [r for r in (1, K) if r < N]
+    score, ln, seq, anc = _beam_state(L, N, t_cap, g, t, eos, fin)
+    tok_emb = torch.randn(V, E, generator=g).to(DEV)
+    sqrt_tab = torch.tensor([float(i) ** 0.5 for i in range(t_cap + 2)], dtype=torch.float64).to(DEV)
+    c_src = [torch.randn(N, Hd, generator=g).to(DEV) for _ in range(2)]
+    xh_src = [torch.randn(N, kpad, generator=g).to(DEV, dtype) for _ in range(2)]
+    sz = xh_src[0].element_size()
+
+    def run(fused):
+        cur, nxt = L.BeamState(), L.BeamState()
+        bufs = [tuple(v.clone().to(DEV) for v in (score, ln, seq)), tuple(torch.zeros_like(v).to(DEV) for v in (score, ln, seq))]
+        for st, b in zip((cur, nxt), bufs):
+            st.score, st.len, st.seq = (v.data_ptr() for v in b)
+        parent = torch.full((N,), -1, dtype=torch.int32, device=DEV)
+        live = torch.zeros(1, dtype=torch.int32, device=DEV)
+        c_dst = [torch.zeros_like(v) for v in c_src]
+        xh_dst = [torch.zeros_like(v) for v in xh_src]
+        if fused:
+            d = L.BeamTailDesc()
+            d.logits, d.ld, d.V, d.cur, d.nxt = logits.data_ptr(), V, V, C.addressof(cur), C.addressof(nxt)
+            d.parent, d.live_images, d.sqrt_tab = parent.data_ptr(), live.data_ptr(), sqrt_tab.data_ptr()
+            d.B, d.K, d.n_live_slots, d.t, d.t_cap, d.eos_id, d.finished_in_place = B, K, K, t, t_cap, eos, 1
+            d.tok_emb, d.xt, d.ld_xt, d.dtype, d.H, d.vocab = tok_emb.data_ptr(), xh_dst[0].data_ptr(), kpad, L.dtype_code(dtype), E, V
+            for l in range(2):
+                d.gather_src[2 * l], d.gather_dst[2 * l] = c_src[l].data_ptr(), c_dst[l].data_ptr()
+                d.gather_row_bytes[2 * l] = d.gather_stride_bytes[2 * l] = Hd * 4
+                d.gather_src[2 * l + 1], d.gather_dst[2 * l + 1] = xh_src[l].data_ptr() + E * sz, xh_dst[l].data_ptr() + E * sz
+                d.gather_row_bytes[2 * l + 1], d.gather_stride_bytes[2 * l + 1] = Hd * sz, kpad * sz
+            d.n_gather = 4
+            L.check(L.lib.mic_beam_tail_ex(C.byref(d), L.stream_ptr()), "mic_beam_tail_ex")
+        else:
+            tv, ti = torch.empty(N, K, device=DEV), torch.empty(N, K, dtype=torch.int32, device=DEV)
+            L.check(L.lib.mic_logsoftmax_topk(logits.data_ptr(), V, N, V, K, 1.0, 0, tv.data_ptr(), ti.data_ptr(), None, L.stream_ptr()))
+            L.check(L.lib.mic_beam_select(C.byref(cur), C.byref(nxt), tv.data_ptr(), ti.data_ptr(), parent.data_ptr(), live.data_ptr(),
+                                          sqrt_tab.data_ptr(), B, K, K, t, t_cap, eos, 1, L.stream_ptr()))
+            full = [torch.zeros_like(v) for v in xh_src]
+            srcs = (C.c_void_p * 4)(c_src[0].data_ptr(), xh_src[0].data_ptr(), c_src[1].data_ptr(), xh_src[1].data_ptr())
+            dsts = (C.c_void_p * 4)(c_dst[0].data_ptr(), full[0].data_ptr(), c_dst[1].data_ptr(), full[1].data_ptr())
+            nbytes = (C.c_int32 * 4)(Hd * 4, kpad * sz, Hd * 4, kpad * sz)
+            L.check(L.lib.mic_gather_rows_multi(srcs, dsts, nbytes, 4, parent.data_ptr(), N, L.stream_ptr()), "mic_gather_rows_multi")
+            for l in range(2):
+                xh_dst[l][:, E:E + Hd] = full[l][:, E:E + Hd]
+            L.check(L.lib.mic_embed_pos(bufs[1][2].data_ptr(), t_cap, t + 1, tok_emb.data_ptr(), None, None,
+                                        xh_dst[0].data_ptr(), kpad, L.dtype_code(dtype), N, E, V, L.stream_ptr()))
+        torch.cuda.synchronize()
+        return [v.cpu() for v in bufs[1]] + [parent.cpu(), live.cpu()] + [v.cpu() for v in c_dst] + [v.float().cpu() for v in xh_dst]
+
+    a, b = run(True), run(False)
+    for i in range(5):
+        if i == 0 and K > 4:
+            torch.testing.assert_close(a[0], b[0], rtol=1e-6, atol=1e-6)
+            continue
+        assert torch.equal(a[i], b[i]), f"state field {i} differs"
+    par = a[3].long()
+    assert torch.equal(a[5], c_src[0].cpu()[par]) and torch.equal(a[6], c_src[1].cpu()[par]) and torch.equal(a[5], b[5])
+    assert torch.equal(a[8], b[8])                        # layer 1: recurrent half moved, the rest untouched (zeros)
+    grew = a[1] == t + 2                                  # beams that were extended got an embedding row
+    assert grew.any() and torch.equal(a[7][grew], b[7][grew])
+    assert torch.equal(a[7][:, E:], b[7][:, E:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,Hd", [(7, 512), (64, 256), (5, 96), (3, 1024)])
+def test_lstm_cell_with_layernorm_equals_the_two_launches(amd, N, Hd, dtype):
+    L = amd._lib
+    g = torch.Generator().manual_seed(N + Hd)
+    gates = torch.randn(N, 4 * Hd, generator=g).to(DEV)
+    c0 = torch.randn(N, Hd, generator=g).to(DEV)
+    ga, be = (1 + 0.3 * torch.randn(Hd, generator=g)).to(DEV), (0.3 * torch.randn(Hd, generator=g)).to(DEV)
+    ld0, ldn = Hd + 8, Hd + 16
+    assert L.lib.mic_lstm_cell_ln_supported(Hd) == 1 and L.lib.mic_lstm_cell_ln_supported(1030) == 0
+    out = []
+    for fused in (True, False):
+        c, h = c0.clone(), torch.zeros(N, Hd, device=DEV)
+        ht0 = torch.zeros(N, ld0, device=DEV, dtype=dtype)
+        hn, hnt = torch.zeros(N, Hd, device=DEV), torch.zeros(N, ldn, device=DEV, dtype=dtype)
+        if fused:
+            L.check(L.lib.mic_lstm_cell_ln(gates.data_ptr(), c.data_ptr(), h.data_ptr(), ht0.data_ptr(), ld0, ga.data_ptr(), be.data_ptr(),
+                                           hn.data_ptr(), hnt.data_ptr(), ldn, L.dtype_code(dtype), N, Hd, L.stream_ptr()), "mic_lstm_cell_ln")
+        else:
+            L.check(L.lib.mic_lstm_cell(gates.data_ptr(), c.data_ptr(), h.data_ptr(), ht0.data_ptr(), ld0, None, 0, L.dtype_code(dtype), N, Hd,
+                                        L.stream_ptr()))
+            L.check(L.lib.mic_layernorm(h.data_ptr(), ga.data_ptr(), be.data_ptr(), hn.data_ptr(), hnt.data_ptr(), ldn, L.dtype_code(dtype), N, Hd,
+                                        L.stream_ptr()))
+        torch.cuda.synchronize()
+        out.append([v.float().cpu() for v in (c, h, ht0, hn, hnt)])
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    for x, y in zip(*out):
+        torch.testing.assert_close(x, y, **tol)
+    i, f, gg, o = gates.cpu().double().chunk(4, dim=1)
+    cn = torch.sigmoid(f) * c0.cpu().double() + torch.sigmoid(i) * torch.tanh(gg)
+    hn_ref = torch.nn.functional.layer_norm(torch.sigmoid(o) * torch.tanh(cn), (Hd,), ga.cpu().double(), be.cpu().double(), 1e-5)
+    torch.testing.assert_close(out[0][3].double(), hn_ref, rtol=1e-4, atol=1e-4)
