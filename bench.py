@@ -362,7 +362,7 @@ def main():
             "config": {"workload": wl["label"] if B == wl["batch"] else wl["label"].replace(f"batch {wl['batch']}", f"batch {B}"),
                        "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}",
                        "lanes_per_gpu": n_lanes},
-            "roofline": {"bound": "mfma", "kernel": ("igemm_kernel<f32>" if ks == 0 else "igemm_kernel<bf16> and fused_block_kernel") +
+            "roofline": {"bound": "mfma", "kernel": ("igemm_kernel<f32>" if ks == 0 else "igemm_kernel<bf16>, fused_block_kernel and stem_pool_kernel") +
                          " (the encoder's convolution launches with tiles of 128 rows and more)", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic if args.workload == "transformer" and B == BATCH else None,

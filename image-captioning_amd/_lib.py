@@ -150,6 +150,8 @@ SIGNATURES = {
     "mic_conv2d": (C.c_int, [P(ConvDesc), vp]),
     "mic_conv2d_variant": (C.c_int, [P(ConvDesc), C.c_int, vp]),
     "mic_conv2d_ln_supported": (C.c_int, [C.c_int]),
+    "mic_stem_pool_supported": (C.c_int, [C.c_int]),
+    "mic_stem_pool": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 7 + [vp]),
     "mic_bottleneck_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mic_bottleneck_fused": (C.c_int, [P(FusedBlockDesc), vp]),
     "mic_profile_begin": (C.c_int, [C.c_int]),

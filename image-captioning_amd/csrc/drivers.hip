@@ -201,20 +201,25 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
     // stem: image -> zero-bordered 4-channel pixels; each of the 7 kernel rows is one run of
     // 8 pixels x 4 channels = 32 contiguous elements (the 8th pixel and 4th channel meet zero weights)
     MIC_TRY(mic_pack_image(images, pack, dt, B, H, W, 3, 3, 3, 5 + (W & 1), s));
+    static const bool no_stem_pool = getenv("MIC_NO_STEM_POOL") != nullptr;  // comparison runs: convolution and pooling as two launches
     {
         const mic_conv_layer& L = net->stem;
         MIC_ARG_CHECK(L.w && L.cout == 64, "mic_resnet50_forward: stem layer not set");
-        mic_conv_desc d{};
-        d.in = pack; d.w = L.w; d.bias = L.bias; d.out = X[1];
-        d.dtype = d.out_dtype = d.res_dtype = dt;
-        d.M = B * p.H1 * p.W1; d.N = 64; d.K = 7 * 32;
-        d.OH = p.H1; d.OW = p.W1; d.IH = p.Hp; d.IW = p.Wp;
-        d.in_img_stride = (int64_t)p.Hp * p.Wp * 4; d.in_row_stride = (int64_t)p.Wp * 4; d.in_pix_stride = 4;
-        d.kw_taps = 1; d.run = 32; d.stride = 2; d.pad_h = d.pad_w = 0;
-        d.ldc = 64; d.relu = 1; d.k_valid = 7 * 7 * 3;
-        MIC_TRY(mic_conv2d(&d, s));
+        if (!no_stem_pool && mic_stem_pool_supported(dt) && L.relu) {
+            MIC_TRY(mic_stem_pool(pack, L.w, L.bias, X[0], dt, B, p.Hp, p.Wp, p.H1, p.W1, 128, s));
+        } else {
+            mic_conv_desc d{};
+            d.in = pack; d.w = L.w; d.bias = L.bias; d.out = X[1];
+            d.dtype = d.out_dtype = d.res_dtype = dt;
+            d.M = B * p.H1 * p.W1; d.N = 64; d.K = 7 * 32;
+            d.OH = p.H1; d.OW = p.W1; d.IH = p.Hp; d.IW = p.Wp;
+            d.in_img_stride = (int64_t)p.Hp * p.Wp * 4; d.in_row_stride = (int64_t)p.Wp * 4; d.in_pix_stride = 4;
+            d.kw_taps = 1; d.run = 32; d.stride = 2; d.pad_h = d.pad_w = 0;
+            d.ldc = 64; d.relu = L.relu; d.k_valid = 7 * 7 * 3;
+            MIC_TRY(mic_conv2d(&d, s));
+            MIC_TRY(mic_maxpool3x3s2(X[1], X[0], dt, B, p.H1, p.W1, 64, s));
+        }
     }
-    MIC_TRY(mic_maxpool3x3s2(X[1], X[0], dt, B, p.H1, p.W1, 64, s));
     int cur = 0, h = p.H2, w = p.W2, bi = 0;
     int nblocks = 0;
     for (int st = 0; st < 4; ++st) nblocks += net->blocks_per_stage[st];

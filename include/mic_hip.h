@@ -105,6 +105,16 @@ int mic_conv2d_ln_supported(int N);
  * for per-variant parity tests.  No reference counterpart. */
 int mic_conv2d_variant(const mic_conv_desc* d, int variant, void* stream);
 
+/* The ResNet stem in one launch (bf16): 7x7 stride-2 convolution (BatchNorm folded) + ReLU + 3x3 stride-2 max-pool with
+ * padding 1 (torchvision resnet50 conv1, bn1, relu, maxpool, reached from models/encoders/transformer.py:46).  `packed` is
+ * the zero-bordered 4-channel image mic_pack_image writes ([B][Hp][Wp][4], border 3 on the top and left, Wp even), w the
+ * stem's weight matrix [>= 64 rows][7*32] with k = kernel row * 32 + pixel * 4 + channel, out [B][H2][W2][64] with
+ * H2 = (H1 - 1) / 2 + 1 for the H1 x W1 convolution output that never reaches memory.  Equals mic_conv2d followed by
+ * mic_maxpool3x3s2 bit for bit. */
+int mic_stem_pool_supported(int dtype);
+int mic_stem_pool(const void* packed, const void* w, const float* bias, void* out, int dtype, int B, int Hp, int Wp, int H1, int W1,
+                  int w_rows, void* stream);
+
 /* Tail of one ResNet bottleneck and head of the next in ONE launch (bf16), for identity blocks (stride 1, no
  * shortcut convolution):
  *     t2  = relu(conv3x3_pad1(t1) + b2)        C -> C channels, kept on chip

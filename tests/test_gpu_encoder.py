@@ -120,3 +120,45 @@ def test_lstm_generate_end_to_end_fp32(amd, trunk_sd):
             caps, none = amd.gen_caption(model, img, vocab, 9, torch.device(DEV), None, K)
             assert none is None
             assert caps == [vocab.encode_as_words(t) for t in ref], (kind, K)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 224, 224), (3, 96, 160), (1, 65, 71), (2, 64, 64), (1, 250, 33)])
+def test_stem_pool_equals_convolution_then_pooling(amd, B, H, W):
+    """The one-launch stem (7x7/2 convolution + ReLU + 3x3/2 max-pool from an LDS-resident image patch) against
+    mic_conv2d + mic_maxpool3x3s2 on the same packed image: bit for bit, over sizes with partial tiles on both axes,
+    odd widths and a map narrower than one tile; and both against torch in fp32 within the bf16 tolerance."""
+    import ctypes as C
+    import torch.nn.functional as F
+    L, Wt = amd._lib, amd.weights
+    g = torch.Generator().manual_seed(H * 7 + W)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    bias = torch.randn(64, generator=g) * 0.2
+    wm = Wt.stem_matrix(w, torch.bfloat16, DEV)
+    d_img, d_b = img.to(DEV), bias.to(DEV)
+    Hp, Wp = H + 6, W + 8 + (W & 1)
+    H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+    pack = torch.empty(B, Hp, Wp, 4, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib.mic_pack_image(d_img.data_ptr(), pack.data_ptr(), L.BF16, B, H, W, 3, 3, 3, 5 + (W & 1), L.stream_ptr()))
+    conv = torch.empty(B, H1, W1, 64, dtype=torch.bfloat16, device=DEV)
+    d = L.ConvDesc()
+    d.in_, d.w, d.bias, d.out = pack.data_ptr(), wm.data_ptr(), d_b.data_ptr(), conv.data_ptr()
+    d.dtype = d.out_dtype = d.res_dtype = L.BF16
+    d.M, d.N, d.K, d.OH, d.OW, d.IH, d.IW = B * H1 * W1, 64, 224, H1, W1, Hp, Wp
+    d.in_img_stride, d.in_row_stride, d.in_pix_stride = Hp * Wp * 4, Wp * 4, 4
+    d.kw_taps, d.run, d.stride, d.ldc, d.relu, d.w_rows = 1, 32, 2, 64, 1, wm.shape[0]
+    L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()))
+    two = torch.empty(B, H2, W2, 64, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib.mic_maxpool3x3s2(conv.data_ptr(), two.data_ptr(), L.BF16, B, H1, W1, 64, L.stream_ptr()))
+    one = torch.full((B, H2, W2, 64), -1.0, dtype=torch.bfloat16, device=DEV)
+    assert L.lib.mic_stem_pool_supported(L.BF16) == 1 and L.lib.mic_stem_pool_supported(L.F32) == 0
+    L.check(L.lib.mic_stem_pool(pack.data_ptr(), wm.data_ptr(), d_b.data_ptr(), one.data_ptr(), L.BF16, B, Hp, Wp, H1, W1, wm.shape[0],
+                                L.stream_ptr()), "mic_stem_pool")
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    ref = F.max_pool2d(F.relu(F.conv2d(img.bfloat16().float(), w.bfloat16().float(), bias, 2, 3)), 3, 2, 1).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(one.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    # a convolution output that does not fit the packed image is refused
+    assert L.lib.mic_stem_pool(pack.data_ptr(), wm.data_ptr(), d_b.data_ptr(), one.data_ptr(), L.BF16, B, Hp, Wp, H1 + 1, W1, wm.shape[0],
+                               L.stream_ptr()) == -1
