@@ -201,6 +201,8 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
     // stem: image -> zero-bordered 4-channel pixels; each of the 7 kernel rows is one run of
     // 8 pixels x 4 channels = 32 contiguous elements (the 8th pixel and 4th channel meet zero weights)
     MIC_TRY(mic_pack_image(images, pack, dt, B, H, W, 3, 3, 3, 5 + (W & 1), s));
+    // every launch from here to the end of the trunk is a convolution on the matrix cores: one pair of profiling events
+    MicProfScope prof_scope(s, dt == MIC_BF16 ? 1 : 0);
     static const bool no_stem_pool = getenv("MIC_NO_STEM_POOL") != nullptr;  // comparison runs: convolution and pooling as two launches
     {
         const mic_conv_layer& L = net->stem;
@@ -346,6 +348,7 @@ extern "C" int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace
     MIC_ARG_CHECK(feats, "mic_tr_cross_kv: null features");
     hipStream_t s = (hipStream_t)stream;
     const int H = dec->H, rows = ws->N / ws->rows_per_image * ws->S;
+    MicProfScope prof_scope(s, dec->dtype == MIC_BF16 ? 1 : 0);  // a run of GEMMs (and one small bias kernel per layer)
     for (int l = 0; l < dec->layers; ++l) {
         const mic_tr_layer& L = dec->layer[l];
         MIC_ARG_CHECK(L.cross_kv_w && ws->cross_kv[l], "mic_tr_cross_kv: layer %d pointers missing", l);

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
 // ---- optional per-launch event timing (mic_profile_begin / mic_profile_end) ----
 struct ProfRec {
     hipEvent_t e0, e1;
-    int slot;
+    int slot, count;  // count: launches between the two events (1, or those a scope gathered)
     double flops;
 };
 std::mutex g_prof_mu;
@@ -592,8 +592,19 @@ std::atomic<bool> g_prof_on{false};  // read outside the lock by every launch
 
 }  // namespace
 
+namespace {
+// A scope brackets a run of back-to-back launches with ONE pair of events: an event between two kernels costs the stream
+// about 5 us, more than many of the launches it would time.  Launches inside a scope add their FLOPs and count to it.
+thread_local ProfRec* t_scope = nullptr;
+thread_local int t_scope_depth = 0;
+}  // namespace
+
 void* mic_prof_open(hipStream_t s, int slot, double flops) {
     if (!g_prof_on) return nullptr;
+    if (t_scope_depth > 0) {
+        if (t_scope) { t_scope->flops += flops; t_scope->count += 1; }
+        return nullptr;
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     if (cap != hipStreamCaptureStatusNone) return nullptr;
@@ -604,6 +615,7 @@ void* mic_prof_open(hipStream_t s, int slot, double flops) {
             rec = &g_prof[g_prof_used++];
             rec->slot = slot;
             rec->flops = flops;
+            rec->count = 1;
         }
     }
     if (rec && hipEventRecord(rec->e0, s) != hipSuccess) return nullptr;
@@ -613,6 +625,27 @@ void* mic_prof_open(hipStream_t s, int slot, double flops) {
 int mic_prof_close(void* rec, hipStream_t s) {
     if (rec) MIC_HIP_CHECK(hipEventRecord(static_cast<ProfRec*>(rec)->e1, s));
     return 0;
+}
+
+MicProfScope::MicProfScope(hipStream_t s, int slot) : stream(s) {
+    if (t_scope_depth++ > 0) return;  // an enclosing scope already owns the events
+    t_scope = nullptr;
+    if (void* rec = mic_prof_open_scope(s, slot)) t_scope = static_cast<ProfRec*>(rec);
+}
+
+MicProfScope::~MicProfScope() {
+    if (--t_scope_depth > 0) return;
+    if (t_scope) (void)hipEventRecord(t_scope->e1, stream);
+    t_scope = nullptr;
+}
+
+void* mic_prof_open_scope(hipStream_t s, int slot) {
+    const int depth = t_scope_depth;
+    t_scope_depth = 0;  // take a record the ordinary way, then empty it
+    ProfRec* rec = static_cast<ProfRec*>(mic_prof_open(s, slot, 0.0));
+    t_scope_depth = depth;
+    if (rec) rec->count = 0;
+    return rec;
 }
 
 namespace {
@@ -833,7 +866,8 @@ extern "C" int mic_profile_end(int32_t count[4], double ms[4], double flops[4]) 
         float t = 0.f;
         MIC_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
         const int v = r.slot;  // 2 * (tile variant) + (bf16)
-        count[v] += 1; ms[v] += t; flops[v] += r.flops;
+        if (r.count == 0) continue;  // a scope nothing was launched in
+        count[v] += r.count; ms[v] += t; flops[v] += r.flops;
     }
     g_prof_used = 0;
     return 0;

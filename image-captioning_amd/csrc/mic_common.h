@@ -49,6 +49,16 @@ void mic_set_error(const char* fmt, ...);
 // of fewer than 128 rows) + (bf16).  close records the closing event.
 void* mic_prof_open(hipStream_t s, int slot, double flops);
 int mic_prof_close(void* rec, hipStream_t s);
+void* mic_prof_open_scope(hipStream_t s, int slot);
+// While one of these lives on a thread, the profiled launches of that thread share its single pair of events (their FLOPs
+// and count are summed into it) instead of recording a pair each.  Meant for runs of back-to-back launches of one slot.
+struct MicProfScope {
+    MicProfScope(hipStream_t s, int slot);
+    ~MicProfScope();
+    MicProfScope(const MicProfScope&) = delete;
+    MicProfScope& operator=(const MicProfScope&) = delete;
+    hipStream_t stream;
+};
 
 // ---- decoder-step internals shared between the drivers ----
 // whether a step on (dec, ws) can take the fused-attention path, the temporary ws->qkvf aside

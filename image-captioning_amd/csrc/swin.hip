@@ -9,6 +9,8 @@
 // padded slots (a zero input row projects to the bias).
 #include "mic_common.h"
 
+#include <memory>
+
 namespace {
 
 constexpr int WIN = 8;          // window side
@@ -371,6 +373,9 @@ extern "C" int mic_swin_forward(const mic_swin* net, const float* images, int B,
     int h = p.PH, w = p.PW, C = net->embed_dim;
     MIC_ARG_CHECK(net->patch_w && net->patch_b && net->patch_g && net->patch_be, "mic_swin_forward: patch embedding not set");
     MIC_TRY(mic_patchify4(images, hbuf, dt, B, H, W, s));
+    // the GEMMs between two window-attention launches run back to back: one pair of profiling events per such run
+    const int prof_slot = dt == MIC_BF16 ? 1 : 0;
+    std::unique_ptr<MicProfScope> scope(new MicProfScope(s, prof_slot));
     static const bool fuse_ln = [] {
         const char* e = getenv("MIC_SWIN_NO_LN_FUSE");  // tuning / comparison runs: LayerNorm as its own launch
         return !(e && atoi(e));
@@ -385,7 +390,9 @@ extern "C" int mic_swin_forward(const mic_swin* net, const float* images, int B,
                           "mic_swin_forward: block %d not set", bi);
             const bool last = st == 3 && k == net->depths[3] - 1;
             MIC_TRY(linear(dt, xt, M, C, Bk.qkv_w, Bk.qkv_b, qkv, dt, 3 * C, MIC_ACT_NONE, s));
+            scope.reset();
             MIC_TRY(mic_window_attn(qkv, Bk.qkv_b, Bk.bias_tab, Bk.logit_scale, o, dt, B, h, w, C, heads, (k & 1) ? WIN / 2 : 0, s));
+            scope.reset(new MicProfScope(s, prof_slot));
             MIC_TRY(linear_ln(dt, o, M, C, Bk.proj_w, Bk.proj_b, Bk.n1_g, Bk.n1_b, x, x, xt, C, u, fuse_ln, s));
             MIC_TRY(linear(dt, xt, M, C, Bk.fc1_w, Bk.fc1_b, hbuf, dt, 4 * C, MIC_ACT_GELU, s));
             MIC_TRY(linear_ln(dt, hbuf, M, 4 * C, Bk.fc2_w, Bk.fc2_b, Bk.n2_g, Bk.n2_b, x, x, last ? out : xt, C, u, fuse_ln, s));
