@@ -26,7 +26,7 @@ def counters(d):
 
 
 def conv_launch(name):
-    return ("igemm_kernelIDF16b" in name and ("Li128ELi" in name or "Li256ELi" in name)) or "fused_block_kernel" in name
+    return ("igemm_kernelIDF16b" in name and ("Li128ELi" in name or "Li256ELi" in name)) or "fused_block_kernel" in name or "stem_pool_kernel" in name
 
 
 def traffic(fetch_dir, write_dir, out, calls):
@@ -46,7 +46,7 @@ def traffic(fetch_dir, write_dir, out, calls):
         if conv_launch(k):
             agg[0] += n; agg[1] += sum(fv); agg[2] += sum(wv)
     res["igemm_bf16_128row_tiles"] = {
-        "what": "igemm_kernel<bf16> launches with tiles of 128 rows and more plus fused_block_kernel launches (the encoder's convolutions)",
+        "what": "igemm_kernel<bf16> launches with tiles of 128 rows and more plus fused_block_kernel and stem_pool_kernel launches (the encoder's convolutions)",
         "launches": agg[0], "hbm_bytes_per_launch": (2 * agg[1] + agg[2]) * 1024 / max(1, agg[0]),
         "fetch_gb_per_generate_corrected": 2 * agg[1] * 1024 / calls / 1e9, "write_gb_per_generate": agg[2] * 1024 / calls / 1e9}
     json.dump(res, open(out, "w"), indent=1)
