@@ -113,6 +113,7 @@ FOLD_MAX_HEADS = 2
 class TrLayer(C.Structure):
     _fields_ = ([(n, vp) for n in _TR_W + _TR_B + _TR_LN + ["self_out_wf", "cross_out_wf", "ff2_wf", "self_in_wf", "cross_q_wf", "ff1_wf"]]
                 + [("cross_kf_w", vp * FOLD_MAX_HEADS), ("cross_vf_w", vp * FOLD_MAX_HEADS), ("cross_qb_scaled", vp),
+                   ("cross_kfc_w", vp), ("cross_vfc_w", vp), ("cross_kfc_b", vp), ("cross_vfc_b", vp), ("cross_cu", vp), ("cross_c0", vp),
                    ("self_qkvf_wf", vp), ("self_qkvf_b", vp), ("self_of_b", vp)])
 
 
@@ -179,6 +180,7 @@ SIGNATURES = {
     "mic_cross_attn_folded": (C.c_int, [P(LnRef), vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, f32, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, vp]),
     "mic_cross_fold_bias": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mic_cross_fold_c": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_attn_fused_supported": (C.c_int, [C.c_int] * 6),
     "mic_attn_fused": (C.c_int, [P(AttnFusedDesc), vp]),
     "mic_beam_tail_supported": (C.c_int, [C.c_int, C.c_int]),

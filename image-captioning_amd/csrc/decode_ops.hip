@@ -892,6 +892,34 @@ __global__ __launch_bounds__(256) void cross_fold_bias_kernel(const T* __restric
     if (lane == 0) c[id] = s;
 }
 
+// c[row][h] = feats[row] . u[h] + c0[h]: the same per-position constant computed from the image tokens themselves
+// (u_h = W_k,h^T b_q,h / sqrt d), for callers that project the folded keys straight from the tokens and never form k.
+template <typename T>
+__global__ __launch_bounds__(256) void cross_fold_c_kernel(const T* __restrict__ feats, const float* __restrict__ u, const float* __restrict__ c0,
+                                                           float* __restrict__ c, int rows, int H, int heads) {
+    constexpr int VEC = Vec16<T>::N;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s[MIC_FOLD_MAX_HEADS];
+#pragma unroll
+    for (int h = 0; h < MIC_FOLD_MAX_HEADS; ++h) s[h] = 0.f;
+    for (int ch = lane; ch < H / VEC; ch += 64) {
+        const Vec16<T> f = ld16(feats + (long long)row * H + ch * VEC);
+#pragma unroll
+        for (int h = 0; h < MIC_FOLD_MAX_HEADS; ++h)
+            if (h < heads) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[h] = fmaf(u[h * H + ch * VEC + e], to_f32<T>(f.v[e]), s[h]);
+            }
+    }
+#pragma unroll
+    for (int h = 0; h < MIC_FOLD_MAX_HEADS; ++h)
+        if (h < heads) {
+            const float t = wave_sum(s[h]);
+            if (lane == 0) c[(long long)row * heads + h] = t + c0[h];
+        }
+}
+
 template <typename T, int RG, int HEADS, bool MULTI> int launch_cross_fold_rg(const FoldArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)a.R * a.H + RG * HEADS * 64 + 8 * RG * (size_t)a.H + 2 * a.R);
     MIC_ARG_CHECK(lds <= 150 * 1024, "mic_cross_attn_folded: %zu bytes of LDS needed", lds);
@@ -1185,6 +1213,20 @@ extern "C" int mic_cross_fold_bias(const void* kv, const float* q_bias_scaled, f
         MIC_LAUNCH(cross_fold_bias_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)kv, q_bias_scaled, c, rows, H, heads);
     else
         MIC_LAUNCH(cross_fold_bias_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)kv, q_bias_scaled, c, rows, H, heads);
+    return 0;
+}
+
+extern "C" int mic_cross_fold_c(const void* feats, const float* u, const float* c0, float* c, int dtype, int rows, int H, int heads,
+                                void* stream) {
+    MIC_ARG_CHECK(feats && u && c0 && c, "mic_cross_fold_c: null pointer");
+    MIC_TRY(check_attn_dims("mic_cross_fold_c", dtype, rows, H, heads));
+    MIC_ARG_CHECK(heads <= MIC_FOLD_MAX_HEADS, "mic_cross_fold_c: %d heads (max %d)", heads, MIC_FOLD_MAX_HEADS);
+    MIC_ARG_CHECK(((uintptr_t)feats & 15) == 0, "mic_cross_fold_c: 16-byte alignment");
+    const int grid = (rows + 3) / 4;
+    if (dtype == MIC_BF16)
+        MIC_LAUNCH(cross_fold_c_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feats, u, c0, c, rows, H, heads);
+    else
+        MIC_LAUNCH(cross_fold_c_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)feats, u, c0, c, rows, H, heads);
     return 0;
 }
 

@@ -343,18 +343,38 @@ int check_tr(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
 }
 }  // namespace
 
+namespace {
+bool chain_shape_ok(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
+bool chain_ok(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
+}  // namespace
+
+// Only the chained steps read the folded keys / values; the plain step (more rows than the chained path takes) reads k and v.
+// A workspace whose shape allows chaining but that has no statistics buffers may still be stepped by mic_tr_step_static,
+// which brings its own: it gets both forms.
 extern "C" int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const void* feats, void* stream) {
     MIC_TRY(check_tr(dec, ws));
     MIC_ARG_CHECK(feats, "mic_tr_cross_kv: null features");
     hipStream_t s = (hipStream_t)stream;
     const int H = dec->H, rows = ws->N / ws->rows_per_image * ws->S;
     MicProfScope prof_scope(s, dec->dtype == MIC_BF16 ? 1 : 0);  // a run of GEMMs (and one small bias kernel per layer)
+    static const bool no_combine = getenv("MIC_NO_CROSS_COMBINE") != nullptr;  // comparison runs: project k, v, then fold
     for (int l = 0; l < dec->layers; ++l) {
         const mic_tr_layer& L = dec->layer[l];
+        const bool fold = use_fold(dec, ws, l) && chain_shape_ok(dec, ws);
+        if (fold && chain_ok(dec, ws) && !no_combine && L.cross_kfc_w && L.cross_vfc_w && L.cross_kfc_b && L.cross_vfc_b && L.cross_cu && L.cross_c0) {
+            // folded keys and values straight from the image tokens: [rows][heads][H] each, then the per-position constant
+            const int heads = dec->heads;
+            MIC_TRY(linear(dec->dtype, feats, H, rows, H, L.cross_kfc_w, L.cross_kfc_b, nullptr, 0, 0, ws->cross_kf[l], dec->dtype,
+                           heads * H, heads * H, 0, s));
+            MIC_TRY(linear(dec->dtype, feats, H, rows, H, L.cross_vfc_w, L.cross_vfc_b, nullptr, 0, 0, ws->cross_vf[l], dec->dtype,
+                           heads * H, heads * H, 0, s));
+            MIC_TRY(mic_cross_fold_c(feats, L.cross_cu, L.cross_c0, ws->cross_c[l], dec->dtype, rows, H, heads, s));
+            continue;
+        }
         MIC_ARG_CHECK(L.cross_kv_w && ws->cross_kv[l], "mic_tr_cross_kv: layer %d pointers missing", l);
         MIC_TRY(linear(dec->dtype, feats, H, rows, H, L.cross_kv_w, L.cross_kv_b, nullptr, 0, 0, ws->cross_kv[l], dec->dtype, 2 * H,
                        2 * H, 0, s));
-        if (use_fold(dec, ws, l)) {
+        if (fold) {
             // K'_h = k_h (W_q,h / sqrt d), V'_h = v_h W_o,h^T as per-head GEMMs over the rows of kv; c_h = b_q,h . k_h
             const int heads = dec->heads, hd = H / heads;
             const size_t sz = mic_dtype_size(dec->dtype);
@@ -531,15 +551,18 @@ int chain_max_rows() {
     return v;
 }
 
-bool chain_ok(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
+// the chained step's conditions on the decoder and the row count (the workspace's statistics buffers aside)
+bool chain_shape_ok(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
     const int H = dec->H;
-    bool chain = ws->N <= chain_max_rows() && ws->stats[0] && ws->stats[1] && dec->out_wf && H % 4 == 0 && H <= 1024;
+    bool chain = ws->N <= chain_max_rows() && dec->out_wf && H % 4 == 0 && H <= 1024;
     for (int l = 0; l < dec->layers && chain; ++l) {
         const mic_tr_layer& Y = dec->layer[l];
         chain = Y.self_in_wf && Y.self_out_wf && Y.cross_q_wf && Y.cross_out_wf && Y.ff1_wf && Y.ff2_wf;
     }
     return chain;
 }
+
+bool chain_ok(const mic_tr_decoder* dec, const mic_tr_workspace* ws) { return ws->stats[0] && ws->stats[1] && chain_shape_ok(dec, ws); }
 }  // namespace
 
 // Whether a step on (dec, ws) can take the fused-attention path, the temporary ws->qkvf aside (mic_tr_step_static

@@ -279,6 +279,26 @@ def build_tr_decoder(sd: SD, heads: int, dtype: torch.dtype, device) -> tuple:
                 Y.cross_kf_w[h] = keep(matrix((wq[h * hd:(h + 1) * hd, :].T * sc).float().contiguous(), dtype, device))
                 Y.cross_vf_w[h] = keep(matrix(wo[:, h * hd:(h + 1) * hd].float().contiguous(), dtype, device))
             Y.cross_qb_scaled = keep(vector((bq * sc).float(), device))
+            # the same fold composed with the key / value projection: K', V' and the per-position constant straight from
+            # the image tokens (two GEMMs per layer where projecting k, v and folding them per head took five)
+            ipw, ipb = sd[p + "cross_attention.mha.in_proj_weight"].double(), sd[p + "cross_attention.mha.in_proj_bias"].double()
+            wk, bk, wv, bv = ipw[H:2 * H], ipb[H:2 * H], ipw[2 * H:], ipb[2 * H:]
+            kw_, kb_, vw_, vb_, cu_, c0_ = [], [], [], [], [], []
+            for h in range(heads):
+                sl = slice(h * hd, (h + 1) * hd)
+                kw_.append(sc * wq[sl, :].T @ wk[sl, :])
+                kb_.append(sc * wq[sl, :].T @ bk[sl])
+                vw_.append(wo[:, sl] @ wv[sl, :])
+                vb_.append(wo[:, sl] @ bv[sl])
+                cu_.append(sc * wk[sl, :].T @ bq[sl])
+                c0_.append(sc * (bk[sl] @ bq[sl]))
+            if H % e == 0:
+                Y.cross_kfc_w = keep(matrix(torch.cat(kw_, dim=0).float().contiguous(), dtype, device))
+                Y.cross_vfc_w = keep(matrix(torch.cat(vw_, dim=0).float().contiguous(), dtype, device))
+                Y.cross_kfc_b = keep(vector(torch.cat(kb_).float(), device))
+                Y.cross_vfc_b = keep(vector(torch.cat(vb_).float(), device))
+                Y.cross_cu = keep(vector(torch.cat(cu_).float(), device))
+                Y.cross_c0 = keep(vector(torch.stack(c0_).float(), device))
         if heads <= L.FOLD_MAX_HEADS and H % e == 0:
             # fold the self-attention output projection into the value rows of the packed in-projection
             # (mic_attn_fused): v'_h = (W_o[:, head h] W_v[head h, :]) x, and the value bias moves into the output bias

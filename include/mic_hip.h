@@ -300,6 +300,10 @@ int mic_cross_attn_folded(const mic_ln_ref* x_ln, const void* kf, const void* vf
                           int accumulate, int dtype, int N, int H, int heads, void* stream);
 /* c[row][h] = q_bias_scaled[h-th slice] . k[row][h-th slice] for `rows` key rows of kv [rows][2H] (k then v). */
 int mic_cross_fold_bias(const void* kv, const float* q_bias_scaled, float* c, int dtype, int rows, int H, int heads, void* stream);
+/* The same constant from the image tokens: c[row][h] = feats[row] . u[h] + c0[h] (u: [heads][H] fp32), for decoders that carry
+ * the combined matrices of mic_tr_layer (cross_cu, cross_c0).  No reference counterpart beyond the bias term of
+ * nn.MultiheadAttention's query projection (models/transformer.py:136). */
+int mic_cross_fold_c(const void* feats, const float* u, const float* c0, float* c, int dtype, int rows, int H, int heads, void* stream);
 
 /* Both attention sub-layers of a post-LN decoder layer for one new position in ONE launch, one workgroup per image
  * (models/transformer.py:81-86 CausalSelfAttention on the newest position, :100 its residual + LayerNorm, :136-140
@@ -536,6 +540,13 @@ typedef struct mic_tr_layer {
     const void* cross_kf_w[2];
     const void* cross_vf_w[2];
     const float* cross_qb_scaled;
+    /* Optional: the key / value projection and the fold above as ONE matrix each, applied to the image tokens directly:
+     * cross_kfc_w = [W_q,h^T W_k,h / sqrt(d) for each head] ([heads*H padded][H]) with bias cross_kfc_b = W_q,h^T b_k,h / sqrt(d),
+     * cross_vfc_w = [W_o[:,h] W_v,h for each head] with bias W_o[:,h] b_v,h, and for the per-position constant
+     * cross_cu = W_k,h^T b_q,h / sqrt(d) ([heads][H] fp32), cross_c0 = b_k,h . b_q,h / sqrt(d) ([heads]).  With them
+     * mic_tr_cross_kv is two GEMMs and one small launch per layer instead of five GEMMs, and never forms k and v. */
+    const void *cross_kfc_w, *cross_vfc_w;
+    const float *cross_kfc_b, *cross_vfc_b, *cross_cu, *cross_c0;
     /* optional, for at most MIC_FOLD_MAX_HEADS heads: the self-attention in-projection with the output projection
      * folded into the value rows, in fragment order: rows [W_q ; W_k ; W_o[:, head 0] W_v[head 0] ; ...] ((2+heads)H rows,
      * padded to 128), its bias [b_q ; b_k ; 0 ...] and self_of_b = b_o + sum_h W_o[:, head h] b_v[head h].  With them, the
