@@ -187,6 +187,7 @@ SIGNATURES = {
     "mic_beam_tail": (C.c_int, [vp, C.c_int, C.c_int, P(BeamState), P(BeamState), vp, vp, vp] + [C.c_int] * 6 + [vp, vp, vp, vp]
                       + [C.c_int] * 3 + [vp]),
     "mic_beam_tail_ex": (C.c_int, [P(BeamTailDesc), vp]),
+    "mic_beam_init": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mic_lstm_cell": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_lstm_cell_ln_supported": (C.c_int, [C.c_int]),
     "mic_lstm_cell_ln": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

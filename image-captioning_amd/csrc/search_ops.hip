@@ -681,6 +681,28 @@ extern "C" int mic_beam_tail(const float* logits, int ld, int V, const mic_beam_
     return mic_beam_tail_ex(&d, stream);
 }
 
+namespace {
+__global__ void beam_init_kernel(const mic_beam_state a, const mic_beam_state b, int32_t* __restrict__ live, int N, int t_cap, int sos) {
+    const long long total = (long long)N * t_cap;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        a.seq[i] = sos; b.seq[i] = sos;
+        if (a.anc) a.anc[i] = 0;
+        if (b.anc) b.anc[i] = 0;
+        if (i < N) { a.score[i] = 0.0; b.score[i] = 0.0; a.len[i] = 1; b.len[i] = 1; }
+        if (live && i < t_cap) live[i] = 0;
+    }
+}
+}  // namespace
+
+extern "C" int mic_beam_init(const mic_beam_state st[2], int32_t* live_images, int N, int t_cap, int sos_id, void* stream) {
+    MIC_ARG_CHECK(st && N > 0 && t_cap > 0, "mic_beam_init: bad arguments");
+    for (int i = 0; i < 2; ++i) MIC_ARG_CHECK(st[i].score && st[i].len && st[i].seq, "mic_beam_init: null state");
+    long long g = ((long long)N * t_cap + 255) / 256;
+    if (g > 2048) g = 2048;
+    MIC_LAUNCH(beam_init_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, st[0], st[1], live_images, N, t_cap, sos_id);
+    return 0;
+}
+
 extern "C" int mic_beam_finalize(const mic_beam_state* st, const double* sqrt_tab, int B, int K, int t_cap, int32_t* tokens,
                                  int32_t* lengths, float* score, const float* attn_hist, int S, float* attn_out, void* stream) {
     MIC_ARG_CHECK(st && st->score && st->len && st->seq && sqrt_tab && tokens && lengths && score, "mic_beam_finalize: null pointer");

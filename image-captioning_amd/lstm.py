@@ -213,10 +213,8 @@ class ImageCaptioner:
                                   torch.empty(N, K, dtype=torch.int32, device=dev), sqrt_tab)
         wss, tts, st, keep, parent, live, top_val, top_idx, sqrt_tab = self._buffers[key]
         self._init_state(feats, K, wss[0], tts[0])
-        for score, ln, seq in keep:
-            score.zero_(); ln.fill_(1); seq.fill_(sos)
-        live.zero_()
         stream = L.stream_ptr()
+        L.check(L.lib.mic_beam_init(st, live.data_ptr(), N, t_cap, sos, stream), "mic_beam_init")
         steps, s = 0, 0
         while s < max_len:
             e = min(max_len, s + self.sync_every)

@@ -236,10 +236,8 @@ class ImageCaptioner:
             t["beam"] = (st, bufs, torch.empty(N, dtype=torch.int32, device=dev), torch.empty(max(t_cap, 1), dtype=torch.int32, device=dev),
                          sqrt_tab)
         st, bufs, parent, live, sqrt_tab = t["beam"]
-        for score_, len_, seq_, anc_ in bufs:
-            score_.zero_(); len_.fill_(1); seq_.fill_(sos); anc_.zero_()
-        live.zero_()
         stream = L.stream_ptr()
+        L.check(L.lib.mic_beam_init(st, live.data_ptr(), N, t_cap, sos, stream), "mic_beam_init")
         L.check(L.lib.mic_tr_cross_kv(C.byref(self.dec), C.byref(ws), feats.data_ptr(), stream), "mic_tr_cross_kv")
         eos = self.vocab.str_to_idx(EOS)
         t0 = 0

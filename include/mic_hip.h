@@ -387,6 +387,11 @@ typedef struct mic_beam_state {
     int32_t* anc;     /* may be NULL (LSTM path keeps no ancestry) */
 } mic_beam_state;
 
+/* Start of a search: both states get score 0, length 1, every sequence position the start token, ancestry 0 (when kept),
+ * and the t_cap live-image counters are cleared (live_images may be NULL) - the list initialisation at
+ * models/transformer.py:589-596 and models/image_captioner.py:117-121 for all images in one launch. */
+int mic_beam_init(const mic_beam_state st[2], int32_t* live_images, int N, int t_cap, int sos_id, void* stream);
+
 /* One beam-search selection step for every image (models/transformer.py:613-628 when
  * finished_in_place == 0, models/image_captioner.py:128-149 when 1): extend each live slot by its K
  * best tokens (top_val/top_idx [B*K][K]), pool with finished slots, stable-sort by
