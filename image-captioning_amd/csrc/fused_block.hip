@@ -40,7 +40,7 @@ struct FusedArgs {
     int dbg;  // timing experiments only (MIC_FUSED_DEBUG): bit 0 skips phase 1, 1 phase 2, 2 its epilogue, 3 the copy-out, 4 phase 3
 };
 
-__device__ __forceinline__ int lds_off(int row, int q) { return row * 64 + ((q ^ (((row >> 3) & 1) << 1)) << 4); }
+__device__ __forceinline__ int lds_off(int row, int q) { return row * 64 + ((q ^ ((row >> 2) & 3)) << 4); }
 
 typedef unsigned int u32x4_fwd __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mma(const u32x4_fwd& wf, const u32x4_fwd& xf, f32x4_t& acc) {
