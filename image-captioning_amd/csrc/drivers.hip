@@ -117,8 +117,9 @@ inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 // dense linear layer y[M][ldc] = act(x[M][ld_in] * W^T + b + res)
 int linear(int dtype, const void* x, int ld_in, int M, int K, const void* w, const float* bias, const void* res, int res_dtype,
-           int ld_res, void* out, int out_dtype, int ldc, int N, int relu, hipStream_t s) {
+           int ld_res, void* out, int out_dtype, int ldc, int N, int relu, hipStream_t s, int k_valid = 0) {
     mic_conv_desc d{};
+    d.k_valid = k_valid;
     d.in = x; d.w = w; d.bias = bias; d.res = res; d.out = out;
     d.dtype = dtype; d.out_dtype = out_dtype; d.res_dtype = res_dtype;
     d.M = M; d.N = N; d.K = K;
@@ -364,10 +365,11 @@ extern "C" int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace
         if (fold && chain_ok(dec, ws) && !no_combine && L.cross_kfc_w && L.cross_vfc_w && L.cross_kfc_b && L.cross_vfc_b && L.cross_cu && L.cross_c0) {
             // folded keys and values straight from the image tokens: [rows][heads][H] each, then the per-position constant
             const int heads = dec->heads;
+            // FLOP accounting: each stands for the H x H key (value) projection of the unfolded layer, not for its heads-fold width
             MIC_TRY(linear(dec->dtype, feats, H, rows, H, L.cross_kfc_w, L.cross_kfc_b, nullptr, 0, 0, ws->cross_kf[l], dec->dtype,
-                           heads * H, heads * H, 0, s));
+                           heads * H, heads * H, 0, s, H / heads));
             MIC_TRY(linear(dec->dtype, feats, H, rows, H, L.cross_vfc_w, L.cross_vfc_b, nullptr, 0, 0, ws->cross_vf[l], dec->dtype,
-                           heads * H, heads * H, 0, s));
+                           heads * H, heads * H, 0, s, H / heads));
             MIC_TRY(mic_cross_fold_c(feats, L.cross_cu, L.cross_c0, ws->cross_c[l], dec->dtype, rows, H, heads, s));
             continue;
         }
