@@ -14,15 +14,28 @@ struct KV {
 // a ranks before b: larger key first, lower index on ties
 __device__ __forceinline__ bool before(const KV& a, const KV& b) { return a.key > b.key || (a.key == b.key && a.idx < b.idx); }
 
+// The wave's first-ranked entry, returned to every lane: quad permutes and row mirrors on the data-parallel-primitive path
+// within each row of 16 lanes (as wave_max), then the four row winners are read into scalar registers and ranked there.
 __device__ __forceinline__ KV wave_best(KV v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        KV t;
-        t.key = __shfl_xor(v.key, o, 64);
-        t.idx = __shfl_xor(v.idx, o, 64);
-        if (before(t, v)) v = t;
+#define MIC_BEST_STEP(ctrl)                                                                                   \
+    {                                                                                                         \
+        KV t;                                                                                                 \
+        t.key = MIC_DPP_F32(v.key, ctrl);                                                                     \
+        t.idx = __builtin_amdgcn_update_dpp(0, v.idx, ctrl, 0xf, 0xf, false);                                 \
+        if (before(t, v)) v = t;                                                                              \
     }
-    return v;
+    MIC_BEST_STEP(0xB1)   // quad_perm [1,0,3,2]
+    MIC_BEST_STEP(0x4E)   // quad_perm [2,3,0,1]
+    MIC_BEST_STEP(0x141)  // row_half_mirror
+    MIC_BEST_STEP(0x140)  // row_mirror: every lane holds the best of its row of 16
+#undef MIC_BEST_STEP
+    KV r = KV{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.key), 0)), __builtin_amdgcn_readlane(v.idx, 0)};
+#pragma unroll
+    for (int l = 16; l < 64; l += 16) {
+        const KV t{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.key), l)), __builtin_amdgcn_readlane(v.idx, l)};
+        if (before(t, r)) r = t;
+    }
+    return r;
 }
 
 __device__ __forceinline__ float block_max(float v, float* red) {
