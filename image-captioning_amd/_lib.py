@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
 class FusedBlockDesc(C.Structure):
     _fields_ = [("t1", vp), ("w2", vp), ("b2", vp), ("w3", vp), ("b3", vp), ("res", vp), ("xout", vp), ("w1n", vp), ("b1n", vp),
                 ("t1n", vp), ("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("C2", i32),
-                ("w2_rows", i32), ("w3_rows", i32), ("w1n_rows", i32)]
+                ("w2_rows", i32), ("w3_rows", i32), ("w1n_rows", i32), ("xs", vp), ("CS", i32)]
 
 
 class LnRef(C.Structure):
@@ -151,6 +151,7 @@ SIGNATURES = {
     "mic_conv2d": (C.c_int, [P(ConvDesc), vp]),
     "mic_conv2d_variant": (C.c_int, [P(ConvDesc), C.c_int, vp]),
     "mic_conv2d_ln_supported": (C.c_int, [C.c_int]),
+    "mic_bottleneck_fused_shortcut_supported": (C.c_int, [C.c_int] * 4),
     "mic_stem_pool_supported": (C.c_int, [C.c_int]),
     "mic_stem_pool": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 7 + [vp]),
     "mic_bottleneck_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),

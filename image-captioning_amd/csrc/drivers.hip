@@ -261,6 +261,33 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
                 cur ^= 1;
                 continue;
             }
+            {
+                // first block of a stage whose shortcut convolution has stride 1 (ResNet-50: stage 0): the same launch with
+                // the shortcut as a second K segment of the expansion (the stage's fused tail matrix [W3 | W_downsample])
+                const mic_fused_tail& F0 = net->tail[st];
+                const mic_conv_layer* nx = bi + 1 < nblocks ? &net->conv[bi + 1][0] : nullptr;
+                const bool shape = k == 0 && L[3].cout > 0 && F0.w && F0.skip_stride == 1 && L[3].stride == 1 && L[3].kh == 1 && L[3].kw == 1 &&
+                                   L[3].pad == 0 && L[0].stride == 1 && L[0].kh == 1 && L[0].relu && L[1].stride == 1 && L[1].kh == 3 &&
+                                   L[1].kw == 3 && L[1].pad == 1 && L[1].relu && L[1].cin == L[1].cout && L[2].kh == 1 && L[2].stride == 1 &&
+                                   L[2].relu && L[2].cin == L[1].cout && L[2].cout == 4 * L[1].cout && F0.cin_main == L[1].cout &&
+                                   F0.cin_skip == L[3].cin && F0.cout == L[2].cout && nx && nx->w && nx->kh == 1 && nx->kw == 1 &&
+                                   nx->stride == 1 && nx->pad == 0 && nx->cin == L[2].cout && nx->relu;
+                if (!no_fusion && shape && mic_bottleneck_fused_shortcut_supported(dt, L[1].cout, nx->cout, F0.cin_skip)) {
+                    const int C = L[1].cout;
+                    if (!have_t1) MIC_TRY(conv_layer(dt, L[0], X[cur], B, h, w, nullptr, T1, &h1, &w1, s));
+                    mic_fused_block_desc d{};
+                    d.t1 = T1; d.w2 = L[1].w; d.b2 = L[1].bias; d.w3 = F0.w; d.b3 = F0.bias; d.xs = X[cur]; d.CS = F0.cin_skip;
+                    d.xout = (bi == nblocks - 1) ? out : X[cur ^ 1];
+                    d.dtype = dt; d.B = B; d.H = h; d.W = w; d.C = C; d.C2 = nx->cout;
+                    d.w2_rows = (C + 127) / 128 * 128; d.w3_rows = (4 * C + 127) / 128 * 128;
+                    d.w1n = nx->w; d.b1n = nx->bias; d.t1n = T2; d.w1n_rows = (nx->cout + 127) / 128 * 128;
+                    MIC_TRY(mic_bottleneck_fused(&d, s));
+                    { void* t = T1; T1 = T2; T2 = t; }
+                    have_t1 = true;
+                    cur ^= 1;
+                    continue;
+                }
+            }
             if (!have_t1) MIC_TRY(conv_layer(dt, L[0], X[cur], B, h, w, nullptr, T1, &h1, &w1, s));
             have_t1 = false;
             MIC_TRY(conv_layer(dt, L[1], T1, B, h1, w1, nullptr, T2, &h2, &w2, s));

@@ -31,7 +31,8 @@ struct FusedArgs {
     const float* b2;     // [C]
     const bf16_t* w3;    // [4C][C]
     const float* b3;     // [4C]
-    const bf16_t* res;   // [M][4C]
+    const bf16_t* res;   // [M][4C] (no shortcut segment)
+    const bf16_t* xs;    // [M][CS]: input of the shortcut convolution (CS > 0), k-columns C .. C+CS-1 of w3
     bf16_t* xout;        // [M][4C]
     const bf16_t* w1n;   // [C2 padded to 128][4C] or nullptr
     const float* b1n;    // [C2]
@@ -57,11 +58,14 @@ struct alignas(8) B4 {
 
 // C: channels of the 3x3 convolution (64 or 128); C2: output channels of the next block's first convolution
 // fused behind it (0: none).
-template <int C, int C2>
+// CS: channels of a stride-1 shortcut convolution folded into the expansion as a second K segment (the first block of a
+// stage: x' = relu([t2 | x] * [W3 | Wds]^T + b), no residual add); 0: the identity block with its residual tile.
+template <int C, int C2, int CS = 0>
 __global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) {
     constexpr int BM = 128, NB = 64, NOUT = 4 * C, NCH = NOUT / NB;
     constexpr int KT1 = 9 * C / 32;          // k-tiles of phase 1
-    constexpr int KT2 = C / 32;              // k-tiles of phase 2
+    constexpr int KC = C + CS;               // K of phase 2
+    constexpr int KT2 = KC / 32;             // k-tiles of phase 2
     constexpr int TN1 = C / 32;              // 16-channel tiles per wave, phase 1 (wave owns C/2 channels)
     constexpr int TN3 = C2 > 0 ? C2 / 32 : 1;
     constexpr int WC1 = C / 64;              // staged weight rows per thread per k-tile, phase 1
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) 
 #pragma unroll
         for (int i = 0; i < NWA; ++i) {  // the slice is 64 whole rows of W3: one contiguous block
             const int c = tid + 256 * i;
-            pwa[i] = *reinterpret_cast<const u32x4*>(a.w3 + (long long)nc * NB * C + c * 8);
+            pwa[i] = *reinterpret_cast<const u32x4*>(a.w3 + (long long)nc * NB * KC + c * 8);
         }
         if constexpr (C2 > 0) {
 #pragma unroll
@@ -189,17 +193,19 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) 
                 pwb[i] = *reinterpret_cast<const u32x4*>(a.w1n + (long long)row * NOUT + nc * NB + ch * 8);
             }
         }
+        if constexpr (CS == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-            const int m = min(m0 + row, a.M - 1);  // rows past M read the last row; their results are never stored
-            pres[i] = *reinterpret_cast<const u32x4*>(a.res + (long long)m * NOUT + nc * NB + ch * 8);
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+                const int m = min(m0 + row, a.M - 1);  // rows past M read the last row; their results are never stored
+                pres[i] = *reinterpret_cast<const u32x4*>(a.res + (long long)m * NOUT + nc * NB + ch * 8);
+            }
         }
     };
     auto stash = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NWA; ++i) {
-            const int c = tid + 256 * i, row = c / (C / 8), ch = c % (C / 8);
+            const int c = tid + 256 * i, row = c / (KC / 8), ch = c % (KC / 8);
             *reinterpret_cast<u32x4*>(sWa + (ch >> 2) * NB * 64 + lds_off(row, ch & 3)) = pwa[i];
         }
         if constexpr (C2 > 0) {
@@ -209,13 +215,31 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) 
                 *reinterpret_cast<u32x4*>(sWb + (ch >> 2) * C2 * 64 + lds_off(row, ch & 3)) = pwb[i];
             }
         }
+        if constexpr (CS == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-            *reinterpret_cast<u32x4*>(sA3 + (ch >> 2) * BM * 64 + lds_off(row, ch & 3)) = pres[i];
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+                *reinterpret_cast<u32x4*>(sA3 + (ch >> 2) * BM * 64 + lds_off(row, ch & 3)) = pres[i];
+            }
         }
     };
     prefetch(0);
+    if constexpr (CS > 0) {
+        // the shortcut's input tile joins t2 as further k-tiles of the expansion's operand image
+        constexpr int NX = BM * (CS / 8) / 256;
+        u32x4 px[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int c = tid + 256 * i, row = c / (CS / 8), ch = c % (CS / 8);
+            const int m = min(m0 + row, a.M - 1);
+            px[i] = *reinterpret_cast<const u32x4*>(a.xs + (long long)m * CS + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int c = tid + 256 * i, row = c / (CS / 8), ch = c % (CS / 8);
+            *reinterpret_cast<u32x4*>(sA2 + (C / 32 + (ch >> 2)) * BM * 64 + lds_off(row, ch & 3)) = px[i];
+        }
+    }
 
     // ---------------- t2 = relu(acc1 + b2) -> LDS ----------------
 #pragma unroll
@@ -286,7 +310,8 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) 
             for (int i = 0; i < 4; ++i) {
                 const int row = wm * 64 + i * 16 + fr;
                 B4* cell = reinterpret_cast<B4*>(sA3 + wn * BM * 64 + lds_off(row, o >> 3) + (o & 7) * 2);
-                const B4 r = *cell;
+                B4 r{};
+                if constexpr (CS == 0) r = *cell;
                 B4 p;
                 p.v[0] = (bf16_t)fmaxf(acc2[j][i][0] + b.x + (float)r.v[0], 0.f);
                 p.v[1] = (bf16_t)fmaxf(acc2[j][i][1] + b.y + (float)r.v[1], 0.f);
@@ -353,12 +378,12 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) 
     }
 }
 
-template <int C, int C2> int launch_fused(FusedArgs& a, hipStream_t s) {
+template <int C, int C2, int CS = 0> int launch_fused(FusedArgs& a, hipStream_t s) {
     a.tiles = (a.M + 127) / 128;
     static const int dbg = [] { const char* e = getenv("MIC_FUSED_DEBUG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
-    void* rec = mic_prof_open(s, 1, 2.0 * a.M * ((double)9 * C * C + (double)C * 4 * C + (double)4 * C * C2));
-    MIC_LAUNCH((fused_block_kernel<C, C2>), dim3(a.tiles), dim3(256), 0, s, a);
+    void* rec = mic_prof_open(s, 1, 2.0 * a.M * ((double)9 * C * C + (double)(C + CS) * 4 * C + (double)4 * C * C2));
+    MIC_LAUNCH((fused_block_kernel<C, C2, CS>), dim3(a.tiles), dim3(256), 0, s, a);
     return mic_prof_close(rec, s);
 }
 
@@ -368,25 +393,34 @@ extern "C" int mic_bottleneck_fused_supported(int dtype, int C, int C2) {
     return dtype == MIC_BF16 && ((C == 64 && (C2 == 0 || C2 == 64 || C2 == 128)) || (C == 128 && (C2 == 0 || C2 == 128)));
 }
 
+extern "C" int mic_bottleneck_fused_shortcut_supported(int dtype, int C, int C2, int CS) {
+    return dtype == MIC_BF16 && C == 64 && C2 == 64 && CS == 64;
+}
+
 extern "C" int mic_bottleneck_fused(const mic_fused_block_desc* d, void* stream) {
-    MIC_ARG_CHECK(d && d->t1 && d->w2 && d->b2 && d->w3 && d->b3 && d->res && d->xout, "mic_bottleneck_fused: null pointer");
+    MIC_ARG_CHECK(d && d->t1 && d->w2 && d->b2 && d->w3 && d->b3 && d->xout, "mic_bottleneck_fused: null pointer");
     MIC_ARG_CHECK(mic_bottleneck_fused_supported(d->dtype, d->C, d->C2), "mic_bottleneck_fused: unsupported (dtype %d, C=%d, C2=%d)", d->dtype,
                   d->C, d->C2);
+    MIC_ARG_CHECK(d->CS == 0 ? d->res != nullptr && d->xs == nullptr
+                             : d->res == nullptr && d->xs != nullptr && mic_bottleneck_fused_shortcut_supported(d->dtype, d->C, d->C2, d->CS),
+                  "mic_bottleneck_fused: an identity block takes res (CS = 0), a shortcut block xs with a supported CS (got CS=%d)", d->CS);
     MIC_ARG_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && (int64_t)d->B * d->H * d->W < (1ll << 31), "mic_bottleneck_fused: bad geometry %dx%dx%d",
                   d->B, d->H, d->W);
     MIC_ARG_CHECK(d->C2 == 0 || (d->w1n && d->b1n && d->t1n), "mic_bottleneck_fused: the fused next convolution needs w1n, b1n and t1n");
     MIC_ARG_CHECK(d->w2_rows >= 128 && d->w3_rows >= 4 * d->C && (d->C2 == 0 || d->w1n_rows >= 128),
                   "mic_bottleneck_fused: weight matrices shorter than the kernel reads (w2 %d rows, w3 %d, w1n %d)", d->w2_rows, d->w3_rows,
                   d->w1n_rows);
-    const uintptr_t al = (uintptr_t)d->t1 | (uintptr_t)d->w2 | (uintptr_t)d->w3 | (uintptr_t)d->res | (uintptr_t)d->xout | (uintptr_t)d->b2 |
+    const uintptr_t al = (uintptr_t)d->t1 | (uintptr_t)d->w2 | (uintptr_t)d->w3 | (uintptr_t)d->res | (uintptr_t)d->xs | (uintptr_t)d->xout | (uintptr_t)d->b2 |
                          (uintptr_t)d->b3 | (uintptr_t)d->w1n | (uintptr_t)d->b1n | (uintptr_t)d->t1n;
     MIC_ARG_CHECK((al & 15) == 0, "mic_bottleneck_fused: every pointer must be 16-byte aligned");
-    MIC_ARG_CHECK(d->res != (const void*)d->xout && d->t1 != (const void*)d->t1n, "mic_bottleneck_fused: outputs must not alias inputs");
+    MIC_ARG_CHECK(d->res != (const void*)d->xout && d->xs != (const void*)d->xout && d->t1 != (const void*)d->t1n,
+                  "mic_bottleneck_fused: outputs must not alias inputs");
     FusedArgs a{};
     a.t1 = (const bf16_t*)d->t1; a.w2 = (const bf16_t*)d->w2; a.b2 = d->b2; a.w3 = (const bf16_t*)d->w3; a.b3 = d->b3;
-    a.res = (const bf16_t*)d->res; a.xout = (bf16_t*)d->xout; a.w1n = (const bf16_t*)d->w1n; a.b1n = d->b1n; a.t1n = (bf16_t*)d->t1n;
+    a.res = (const bf16_t*)d->res; a.xs = (const bf16_t*)d->xs; a.xout = (bf16_t*)d->xout; a.w1n = (const bf16_t*)d->w1n; a.b1n = d->b1n; a.t1n = (bf16_t*)d->t1n;
     a.M = d->B * d->H * d->W; a.IH = d->H; a.IW = d->W;
     hipStream_t s = (hipStream_t)stream;
+    if (d->CS > 0) return launch_fused<64, 64, 64>(a, s);
     if (d->C == 64) {
         if (d->C2 == 0) return launch_fused<64, 0>(a, s);
         if (d->C2 == 64) return launch_fused<64, 64>(a, s);

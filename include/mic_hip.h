@@ -136,8 +136,15 @@ typedef struct mic_fused_block_desc {
     void* t1n;            /* [B*H*W][C2] */
     int32_t dtype, B, H, W, C, C2;
     int32_t w2_rows, w3_rows, w1n_rows;  /* rows the weight matrices really have */
+    /* First block of a stage with a stride-1 shortcut convolution (out = conv3(...) + downsample(x), torchvision
+     * Bottleneck.forward): CS > 0 channels of xs [B*H*W][CS] are a second K segment of the expansion, w3 is then
+     * [4C][C + CS] = [W3 | W_downsample] with the summed bias in b3, and res must be NULL
+     * (mic_bottleneck_fused_shortcut_supported: bf16, C = C2 = CS = 64, the first block of ResNet-50's first stage). */
+    const void* xs;
+    int32_t CS;
 } mic_fused_block_desc;
 int mic_bottleneck_fused_supported(int dtype, int C, int C2);
+int mic_bottleneck_fused_shortcut_supported(int dtype, int C, int C2, int CS);
 int mic_bottleneck_fused(const mic_fused_block_desc* d, void* stream);
 
 /* Per-launch timing of the GEMM/conv kernel for roofline reports.  Between begin and end every

@@ -313,6 +313,45 @@ def test_bottleneck_fused_matches_torch(amd, Cm, C2, B, H, Wd):
         np.testing.assert_allclose(keep[9].float().cpu().permute(0, 3, 1, 2).numpy(), tn.numpy(), **tol)
 
 
+@pytest.mark.parametrize("B,H,Wd", [(3, 14, 14), (1, 5, 7), (4, 56, 56)])
+def test_bottleneck_fused_with_shortcut_convolution(amd, B, H, Wd):
+    """The first block of ResNet-50's first stage in one launch: conv3x3+ReLU -> [conv1x1 | shortcut conv1x1 of the block's
+    input] + ReLU -> next conv1x1 + ReLU, against the same chain in torch with bf16 rounding at the stored points."""
+    L, W = amd._lib, amd.weights
+    bf = torch.bfloat16
+    Cm = C2 = CS = 64
+    assert L.lib.mic_bottleneck_fused_shortcut_supported(L.BF16, 64, 64, 64) == 1
+    assert L.lib.mic_bottleneck_fused_shortcut_supported(L.BF16, 128, 128, 256) == 0
+    g = torch.Generator().manual_seed(B + H)
+    r16 = lambda t: t.to(bf).float()
+    t1 = r16(torch.randn(B, Cm, H, Wd, generator=g).relu())
+    x = r16(torch.randn(B, CS, H, Wd, generator=g).relu())
+    w2 = r16(torch.randn(Cm, Cm, 3, 3, generator=g) / math.sqrt(9 * Cm))
+    w3 = r16(torch.randn(4 * Cm, Cm, 1, 1, generator=g) / math.sqrt(Cm))
+    wd = r16(torch.randn(4 * Cm, CS, 1, 1, generator=g) / math.sqrt(CS))
+    b2, b3 = 0.1 * torch.randn(Cm, generator=g), 0.1 * torch.randn(4 * Cm, generator=g)
+    w1n = r16(torch.randn(C2, 4 * Cm, 1, 1, generator=g) / math.sqrt(4 * Cm))
+    b1n = 0.1 * torch.randn(C2, generator=g)
+    t2 = r16(F.relu(F.conv2d(t1, w2, b2, 1, 1)))
+    xo = r16(F.relu(F.conv2d(t2, w3, b3) + F.conv2d(x, wd)))
+    tn = r16(F.relu(F.conv2d(xo, w1n, b1n)))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, bf)
+    w3d = W.conv_matrix(torch.cat([w3, wd], dim=1), bf, DEV)   # [4C][C + CS]
+    keep = [nhwc(t1), W.conv_matrix(w2, bf, DEV), b2.to(DEV), w3d, b3.to(DEV), nhwc(x),
+            torch.full((B, H, Wd, 4 * Cm), 7.0, dtype=bf, device=DEV), W.conv_matrix(w1n, bf, DEV), b1n.to(DEV),
+            torch.full((B, H, Wd, C2), 7.0, dtype=bf, device=DEV)]
+    d = L.FusedBlockDesc()
+    d.t1, d.w2, d.b2, d.w3, d.b3, d.xs, d.xout, d.w1n, d.b1n, d.t1n = (t.data_ptr() for t in keep)
+    d.dtype, d.B, d.H, d.W, d.C, d.C2, d.CS = L.BF16, B, H, Wd, Cm, C2, CS
+    d.w2_rows, d.w3_rows, d.w1n_rows = keep[1].shape[0], keep[3].shape[0], keep[7].shape[0]
+    L.check(L.lib.mic_bottleneck_fused(C.byref(d), L.stream_ptr()), "mic_bottleneck_fused")
+    tol = dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(keep[6].float().cpu().permute(0, 3, 1, 2).numpy(), xo.numpy(), **tol)
+    np.testing.assert_allclose(keep[9].float().cpu().permute(0, 3, 1, 2).numpy(), tn.numpy(), **tol)
+    d.res = keep[5].data_ptr()   # a residual and a shortcut segment at once is refused
+    assert L.lib.mic_bottleneck_fused(C.byref(d), L.stream_ptr()) == -1
+
+
 def test_bottleneck_fused_rejects_bad_arguments(amd):
     L = amd._lib
     d = L.FusedBlockDesc()
