@@ -154,6 +154,7 @@ SIGNATURES = {
     "mic_bottleneck_fused_shortcut_supported": (C.c_int, [C.c_int] * 4),
     "mic_stem_pool_supported": (C.c_int, [C.c_int]),
     "mic_stem_pool": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 7 + [vp]),
+    "mic_stem_pool_conv1": (C.c_int, [vp] * 7 + [C.c_int] * 8 + [vp]),
     "mic_bottleneck_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mic_bottleneck_fused": (C.c_int, [P(FusedBlockDesc), vp]),
     "mic_profile_begin": (C.c_int, [C.c_int]),

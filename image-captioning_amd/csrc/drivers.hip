@@ -204,12 +204,20 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
     MIC_TRY(mic_pack_image(images, pack, dt, B, H, W, 3, 3, 3, 5 + (W & 1), s));
     // every launch from here to the end of the trunk is a convolution on the matrix cores: one pair of profiling events
     MicProfScope prof_scope(s, dt == MIC_BF16 ? 1 : 0);
+    bool stem_t1 = false;  // T1 already holds the first bottleneck's first convolution
     static const bool no_stem_pool = getenv("MIC_NO_STEM_POOL") != nullptr;  // comparison runs: convolution and pooling as two launches
     {
         const mic_conv_layer& L = net->stem;
         MIC_ARG_CHECK(L.w && L.cout == 64, "mic_resnet50_forward: stem layer not set");
         if (!no_stem_pool && mic_stem_pool_supported(dt) && L.relu) {
-            MIC_TRY(mic_stem_pool(pack, L.w, L.bias, X[0], dt, B, p.Hp, p.Wp, p.H1, p.W1, 128, s));
+            // the first bottleneck's 1x1 convolution takes the pooled tile while it is on chip
+            const mic_conv_layer& c1 = net->conv[0][0];
+            if (c1.w && c1.kh == 1 && c1.kw == 1 && c1.stride == 1 && c1.pad == 0 && c1.cin == 64 && c1.cout == 64 && c1.relu) {
+                MIC_TRY(mic_stem_pool_conv1(pack, L.w, L.bias, X[0], c1.w, c1.bias, T1, dt, B, p.Hp, p.Wp, p.H1, p.W1, 128, 128, s));
+                stem_t1 = true;
+            } else {
+                MIC_TRY(mic_stem_pool(pack, L.w, L.bias, X[0], dt, B, p.Hp, p.Wp, p.H1, p.W1, 128, s));
+            }
         } else {
             mic_conv_desc d{};
             d.in = pack; d.w = L.w; d.bias = L.bias; d.out = X[1];
@@ -231,7 +239,7 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
     // expansion + residual + ReLU and the NEXT block's first 1x1 convolution (mic_bottleneck_fused).  `have_t1` says that
     // T1 already holds the first convolution of the block about to run (written by the previous block's launch).
     static const bool no_fusion = getenv("MIC_NO_BLOCK_FUSION") != nullptr;
-    bool have_t1 = false;
+    bool have_t1 = stem_t1;
     for (int st = 0; st < 4; ++st) {
         for (int k = 0; k < net->blocks_per_stage[st]; ++k, ++bi) {
             const mic_conv_layer* L = net->conv[bi];

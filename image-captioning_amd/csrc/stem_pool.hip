@@ -37,6 +37,9 @@ struct StemArgs {
     const bf16_t* w;     // [>= 64][224], k = kernel row * 32 + pixel * 4 + channel
     const float* bias;   // [64]
     bf16_t* out;         // [B][H2][W2][64]
+    const bf16_t* w1;    // optional following 1x1 convolution 64 -> 64 (+ ReLU): [>= 64][64]
+    const float* b1;     // [64]
+    bf16_t* t1;          // [B][H2][W2][64]
     int B, Hp, Wp, H1, W1, H2, W2, tiles_x, tiles_y;
 };
 
@@ -45,6 +48,8 @@ __device__ __forceinline__ int w_off(int row, int q) { return row * 64 + ((q ^ (
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
+// C1: the first 1x1 convolution of the following bottleneck (64 -> 64, ReLU) rides along: the pooled tile is its operand.
+template <bool C1>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     unsigned char* patch = smem;
@@ -144,12 +149,13 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemArgs a) {
     __syncthreads();
 
     // ---- 3x3 / 2 max-pool: non-negative bf16 values order like their bit patterns ----
+    constexpr int NIT = PTH * PTW * 8 / 256;
+    u16x8 pooled[NIT];
 #pragma unroll
-    for (int k = 0; k < PTH * PTW * 8 / 256; ++k) {
+    for (int k = 0; k < NIT; ++k) {
         const int it = tid + 256 * k, pp = it >> 3, ch = it & 7;
         const int ppy = pp / PTW, ppx = pp - ppy * PTW;
         const int py = py0 + ppy, px = px0 + ppx;
-        if (py >= a.H2 || px >= a.W2) continue;
         u16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -158,7 +164,74 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemArgs a) {
                 const u16x8 v = *reinterpret_cast<const u16x8*>(ct + ((2 * ppy + dy) * CTW + 2 * ppx + dx) * CROW_B + ch * 16);
                 m = __builtin_elementwise_max(m, v);
             }
-        *reinterpret_cast<u16x8*>(a.out + (((long long)b * a.H2 + py) * a.W2 + px) * 64 + ch * 8) = m;
+        pooled[k] = m;
+        if (py < a.H2 && px < a.W2) *reinterpret_cast<u16x8*>(a.out + (((long long)b * a.H2 + py) * a.W2 + px) * 64 + ch * 8) = m;
+    }
+    if constexpr (C1) {
+        // ---- t1 = relu(pooled * W1^T + b1): the pooled tile (128 pixels x 64 channels) and W1 as MFMA operand images ----
+        constexpr int A_B = 2 * 128 * 64, W1_B = 2 * 64 * 64, T_OFF = A_B + W1_B;  // bytes; the t1 tile is staged behind them
+        static_assert(T_OFF + 128 * CROW_B <= SMEM, "1x1 stage fits the convolution tile's LDS");
+        u32x4 w1v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            w1v[i] = *reinterpret_cast<const u32x4*>(a.w1 + row * 64 + ch * 8);
+        }
+        __syncthreads();  // every pooling read of the convolution tile is done
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = tid + 256 * k, pp = it >> 3, ch = it & 7;
+            *reinterpret_cast<u16x8*>(smem + (ch >> 2) * 128 * 64 + w_off(pp, ch & 3)) = pooled[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            *reinterpret_cast<u32x4*>(smem + A_B + (ch >> 2) * 64 * 64 + w_off(row, ch & 3)) = w1v[i];
+        }
+        __syncthreads();
+        f32x4_t acc1[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            u32x4 xf[2], wf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(smem + kt * 128 * 64 + w_off(wave * 32 + i * 16 + (lane & 15), lane >> 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const u32x4*>(smem + A_B + kt * 64 * 64 + w_off(j * 16 + (lane & 15), lane >> 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]), __builtin_bit_cast(bf16x8_t, xf[i]),
+                                                                         acc1[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = j * 16 + (lane >> 4) * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(a.b1 + n);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pp = wave * 32 + i * 16 + (lane & 15);
+                struct alignas(8) B4 { bf16_t v[4]; } o;
+                o.v[0] = (bf16_t)fmaxf(acc1[i][j][0] + bv.x, 0.f);
+                o.v[1] = (bf16_t)fmaxf(acc1[i][j][1] + bv.y, 0.f);
+                o.v[2] = (bf16_t)fmaxf(acc1[i][j][2] + bv.z, 0.f);
+                o.v[3] = (bf16_t)fmaxf(acc1[i][j][3] + bv.w, 0.f);
+                *reinterpret_cast<B4*>(smem + T_OFF + pp * CROW_B + n * 2) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = tid + 256 * k, pp = it >> 3, ch = it & 7;
+            const int ppy = pp / PTW, ppx = pp - ppy * PTW;
+            const int py = py0 + ppy, px = px0 + ppx;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + T_OFF + pp * CROW_B + ch * 16);
+            if (py < a.H2 && px < a.W2) *reinterpret_cast<u32x4*>(a.t1 + (((long long)b * a.H2 + py) * a.W2 + px) * 64 + ch * 8) = v;
+        }
     }
 }
 
@@ -166,8 +239,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemArgs a) {
 
 extern "C" int mic_stem_pool_supported(int dtype) { return dtype == MIC_BF16; }
 
-extern "C" int mic_stem_pool(const void* packed, const void* w, const float* bias, void* out, int dtype, int B, int Hp, int Wp, int H1,
-                             int W1, int w_rows, void* stream) {
+namespace {
+int stem_pool_impl(const void* packed, const void* w, const float* bias, void* out, const void* w1, const float* b1, void* t1, int dtype,
+                   int B, int Hp, int Wp, int H1, int W1, int w_rows, int w1_rows, void* stream) {
     MIC_ARG_CHECK(packed && w && bias && out, "mic_stem_pool: null pointer");
     MIC_ARG_CHECK(mic_stem_pool_supported(dtype), "mic_stem_pool: bf16 only (dtype %d)", dtype);
     MIC_ARG_CHECK(B > 0 && H1 > 0 && W1 > 0 && Wp % 2 == 0, "mic_stem_pool: bad sizes B=%d H1=%d W1=%d Wp=%d", B, H1, W1, Wp);
@@ -176,15 +250,36 @@ extern "C" int mic_stem_pool(const void* packed, const void* w, const float* bia
                   Hp, Wp);
     MIC_ARG_CHECK(w_rows >= 64, "mic_stem_pool: weight matrix has %d rows, 64 are read", w_rows);
     MIC_ARG_CHECK((((uintptr_t)packed | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out) & 15) == 0, "mic_stem_pool: pointers must be 16-byte aligned");
+    if (w1) {
+        MIC_ARG_CHECK(b1 && t1 && w1_rows >= 64 && t1 != out, "mic_stem_pool_conv1: the following convolution needs b1, t1 and 64 weight rows (%d)", w1_rows);
+        MIC_ARG_CHECK((((uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)t1) & 15) == 0, "mic_stem_pool_conv1: pointers must be 16-byte aligned");
+    }
     StemArgs a;
     a.img = (const bf16_t*)packed; a.w = (const bf16_t*)w; a.bias = bias; a.out = (bf16_t*)out;
+    a.w1 = (const bf16_t*)w1; a.b1 = b1; a.t1 = (bf16_t*)t1;
     a.B = B; a.Hp = Hp; a.Wp = Wp; a.H1 = H1; a.W1 = W1;
     a.H2 = (H1 + 2 - 3) / 2 + 1; a.W2 = (W1 + 2 - 3) / 2 + 1;
     a.tiles_y = (a.H2 + PTH - 1) / PTH; a.tiles_x = (a.W2 + PTW - 1) / PTW;
     const long long grid = (long long)B * a.tiles_y * a.tiles_x;
     MIC_ARG_CHECK(grid < (1ll << 31), "mic_stem_pool: grid too large");
     // counted with the encoder's other convolution launches: 7*7*3 real products per output and channel
-    void* rec = mic_prof_open((hipStream_t)stream, 1, 2.0 * B * H1 * W1 * 64 * 147);
-    MIC_LAUNCH(stem_pool_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    const double flops = 2.0 * B * H1 * W1 * 64 * 147 + (w1 ? 2.0 * B * a.H2 * a.W2 * 64 * 64 : 0.0);
+    void* rec = mic_prof_open((hipStream_t)stream, 1, flops);
+    if (w1)
+        MIC_LAUNCH(stem_pool_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        MIC_LAUNCH(stem_pool_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     return mic_prof_close(rec, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int mic_stem_pool(const void* packed, const void* w, const float* bias, void* out, int dtype, int B, int Hp, int Wp, int H1,
+                             int W1, int w_rows, void* stream) {
+    return stem_pool_impl(packed, w, bias, out, nullptr, nullptr, nullptr, dtype, B, Hp, Wp, H1, W1, w_rows, 0, stream);
+}
+
+extern "C" int mic_stem_pool_conv1(const void* packed, const void* w, const float* bias, void* out, const void* w1, const float* b1,
+                                   void* t1, int dtype, int B, int Hp, int Wp, int H1, int W1, int w_rows, int w1_rows, void* stream) {
+    MIC_ARG_CHECK(w1, "mic_stem_pool_conv1: null pointer");
+    return stem_pool_impl(packed, w, bias, out, w1, b1, t1, dtype, B, Hp, Wp, H1, W1, w_rows, w1_rows, stream);
 }

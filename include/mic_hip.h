@@ -114,6 +114,11 @@ int mic_conv2d_variant(const mic_conv_desc* d, int variant, void* stream);
 int mic_stem_pool_supported(int dtype);
 int mic_stem_pool(const void* packed, const void* w, const float* bias, void* out, int dtype, int B, int Hp, int Wp, int H1, int W1,
                   int w_rows, void* stream);
+/* The same launch followed, on the pooled tile while it is still on chip, by the first convolution of the bottleneck
+ * that comes next (1x1, 64 -> 64, BatchNorm folded, ReLU; torchvision layer1[0].conv1/bn1/relu): t1 [B][H2][W2][64] =
+ * relu(out * w1^T + b1) with w1 [>= 64 rows][64].  Equals mic_stem_pool followed by mic_conv2d bit for bit. */
+int mic_stem_pool_conv1(const void* packed, const void* w, const float* bias, void* out, const void* w1, const float* b1, void* t1,
+                        int dtype, int B, int Hp, int Wp, int H1, int W1, int w_rows, int w1_rows, void* stream);
 
 /* Tail of one ResNet bottleneck and head of the next in ONE launch (bf16), for identity blocks (stride 1, no
  * shortcut convolution):

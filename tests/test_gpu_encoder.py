@@ -162,3 +162,21 @@ def test_stem_pool_equals_convolution_then_pooling(amd, B, H, W):
     # a convolution output that does not fit the packed image is refused
     assert L.lib.mic_stem_pool(pack.data_ptr(), wm.data_ptr(), d_b.data_ptr(), one.data_ptr(), L.BF16, B, Hp, Wp, H1 + 1, W1, wm.shape[0],
                                L.stream_ptr()) == -1
+    # with the following bottleneck's 1x1 convolution riding along: the same pooled map, and t1 equal to mic_conv2d on it
+    w1 = torch.randn(64, 64, 1, 1, generator=g) * 0.2
+    b1 = (torch.randn(64, generator=g) * 0.2).to(DEV)
+    w1m = Wt.conv_matrix(w1, torch.bfloat16, DEV)
+    t1_two = torch.empty(B, H2, W2, 64, dtype=torch.bfloat16, device=DEV)
+    d = L.ConvDesc()
+    d.in_, d.w, d.bias, d.out = two.data_ptr(), w1m.data_ptr(), b1.data_ptr(), t1_two.data_ptr()
+    d.dtype = d.out_dtype = d.res_dtype = L.BF16
+    d.M, d.N, d.K, d.OH, d.OW, d.IH, d.IW = B * H2 * W2, 64, 64, 1, 1, 1, 1
+    d.in_img_stride, d.in_pix_stride, d.kw_taps, d.run, d.stride, d.ldc, d.relu, d.w_rows = 64, 4, 1, 64, 1, 64, 1, w1m.shape[0]
+    L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()))
+    one2 = torch.full((B, H2, W2, 64), -1.0, dtype=torch.bfloat16, device=DEV)
+    t1_one = torch.full((B, H2, W2, 64), -1.0, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib.mic_stem_pool_conv1(pack.data_ptr(), wm.data_ptr(), d_b.data_ptr(), one2.data_ptr(), w1m.data_ptr(), b1.data_ptr(),
+                                      t1_one.data_ptr(), L.BF16, B, Hp, Wp, H1, W1, wm.shape[0], w1m.shape[0], L.stream_ptr()),
+            "mic_stem_pool_conv1")
+    torch.cuda.synchronize()
+    assert torch.equal(one2, two) and torch.equal(t1_one, t1_two)
