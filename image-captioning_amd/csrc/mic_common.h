@@ -98,10 +98,6 @@ template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>&
     *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, v);
 }
 
-// Wave-wide reductions on the data-parallel-primitive path of the vector ALU (no LDS crossbar round trips): within each
-// row of 16 lanes by quad permutes and row mirrors, then the four row results are read into scalar registers and combined,
-// so every lane returns the same value.
-#define MIC_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
 // LayerNorm pieces shared by the stand-alone kernel and the GEMM epilogue: written with explicit fused multiply-adds and
 // contraction switched off, so both compile to the same arithmetic and produce the same bits from the same inputs.
 __device__ __forceinline__ float ln_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
@@ -115,6 +111,10 @@ __device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float
     return __builtin_fmaf((v - mean) * rstd, g, b);
 }
 
+// Wave-wide reductions on the data-parallel-primitive path of the vector ALU (no LDS crossbar round trips): within each
+// row of 16 lanes by quad permutes and row mirrors, then the four row results are read into scalar registers and combined,
+// so every lane returns the same value.
+#define MIC_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
     v += MIC_DPP_F32(v, 0xB1);   // quad_perm [1,0,3,2]
     v += MIC_DPP_F32(v, 0x4E);   // quad_perm [2,3,0,1]
