@@ -128,7 +128,7 @@ class TrWorkspace(C.Structure):
                 ("kcache", vp * MAX_LAYERS), ("vcache", vp * MAX_LAYERS), ("cross_kv", vp * MAX_LAYERS),
                 ("attn", vp), ("top_val", vp), ("top_idx", vp), ("stats", vp * 2),
                 ("cross_kf", vp * MAX_LAYERS), ("cross_vf", vp * MAX_LAYERS), ("cross_c", vp * MAX_LAYERS),
-                ("qkvf", vp), ("vfcache", vp * MAX_LAYERS)]
+                ("qkvf", vp), ("vfcache", vp * MAX_LAYERS), ("sync", vp)]
 
 
 class LstmDecoder(C.Structure):
@@ -205,6 +205,10 @@ SIGNATURES = {
     "mic_resnet50_forward": (C.c_int, [P(Resnet50), vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]),
     "mic_tr_cross_kv": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, vp]),
     "mic_tr_step": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "mic_tr_step_persistent": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "mic_tr_persist_supported": (C.c_int, [C.c_int] * 8),
+    "mic_tr_step_schedule": (C.c_int, [P(TrDecoder), P(TrWorkspace)]),
+    "mic_tr_persist_sync_words": (C.c_int64, [C.c_int, C.c_int]),
     "mic_tr_step_static": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mic_tr_beam_steps": (C.c_int, [P(TrDecoder), P(TrWorkspace), P(BeamState), vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, vp]),

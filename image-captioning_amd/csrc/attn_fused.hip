@@ -18,6 +18,7 @@
 // are requested as soon as the self-attention keys have been consumed and its folded values as soon as the
 // self-attention values have, so both are in flight during the softmax / LayerNorm in between.
 #include "mic_common.h"
+#include "decode_shared.h"
 
 #include <atomic>
 
@@ -44,57 +45,6 @@ struct FusedAttnArgs {
     float attn_scale;
     int accumulate, t, t_cap, S, R, N;
 };
-
-// v of the lane whose number differs in bit O.  Within a row of 16 lanes this is a data-parallel-primitive move of the
-// vector ALU (quad permutes for 1 and 2, a rotation by 8 within the row for 8); the others go through the LDS crossbar.
-template <int O> __device__ __forceinline__ float lane_xor(float v) {
-    if constexpr (O == 1) return MIC_DPP_F32(v, 0xB1);        // quad_perm [1,0,3,2]
-    else if constexpr (O == 2) return MIC_DPP_F32(v, 0x4E);   // quad_perm [2,3,0,1]
-    else if constexpr (O == 8) return MIC_DPP_F32(v, 0x128);  // row_ror:8
-    else return __shfl_xor(v, O, 64);
-}
-
-// One halving step over lane bit O: a lane keeps HALF of its 2 * HALF values and hands the other half to its partner.
-template <int HALF, int O, int N> __device__ __forceinline__ int halve(float (&v)[N], int lane) {
-    const bool up = (lane & O) != 0;
-#pragma unroll
-    for (int i = 0; i < HALF; ++i) {
-        // the two values are made opaque first: otherwise the selects below are turned into one register-array access
-        // with a runtime index, which is lowered to a compare-and-select chain over all N registers
-        float lo = v[i], hi = v[i + HALF];
-        asm volatile("" : "+v"(lo), "+v"(hi));
-        const float send = up ? lo : hi;
-        const float keep = up ? hi : lo;
-        v[i] = keep + lane_xor<O>(send);
-    }
-    return up ? HALF : 0;
-}
-
-// Sums N values (a power of two, N <= WIDTH) over groups of WIDTH lanes by recursive halving, so that N - 1
-// (+ log2(WIDTH / N)) cross-lane moves do the work of N * log2(WIDTH).  The lane bits are used in the order 1, 2, 8, 4,
-// 16, 32: the steps that move the most values are the cheap in-row ones.  On return v[0] holds the group's total of the
-// value whose index is returned; `writer` is true on one lane of those that hold the same total.
-template <int N, int WIDTH> __device__ __forceinline__ int reduce_scatter(float (&v)[N], int lane, bool& writer) {
-    static_assert(N >= 1 && (N & (N - 1)) == 0 && N <= WIDTH && (WIDTH == 32 || WIDTH == 64), "reduce_scatter sizes");
-    int idx = 0;
-    if constexpr (N >= 2) idx += halve<N / 2, 1>(v, lane);
-    if constexpr (N >= 4) idx += halve<N / 4, 2>(v, lane);
-    if constexpr (N >= 8) idx += halve<N / 8, 8>(v, lane);
-    if constexpr (N >= 16) idx += halve<N / 16, 4>(v, lane);
-    if constexpr (N >= 32) idx += halve<N / 32, 16>(v, lane);
-    if constexpr (N >= 64) idx += halve<N / 64, 32>(v, lane);
-    constexpr int used = N >= 64 ? 63 : N >= 32 ? 31 : N >= 16 ? 15 : N >= 8 ? 11 : N >= 4 ? 3 : N >= 2 ? 1 : 0;
-    if constexpr (!(used & 1)) v[0] += lane_xor<1>(v[0]);
-    if constexpr (!(used & 2)) v[0] += lane_xor<2>(v[0]);
-    if constexpr (!(used & 4)) v[0] += lane_xor<4>(v[0]);
-    if constexpr (!(used & 8)) v[0] += lane_xor<8>(v[0]);
-    if constexpr (!(used & 16)) v[0] += lane_xor<16>(v[0]);
-    if constexpr (!(used & 32) && WIDTH == 64) v[0] += lane_xor<32>(v[0]);
-    writer = (lane & (WIDTH - 1) & ~used) == 0;
-    return idx;
-}
-
-constexpr int pow2_at_least(int n) { return n <= 1 ? 1 : 2 * pow2_at_least((n + 1) / 2); }
 
 // NG: row groups of an image (more than one when it has more rows than a group takes); they run one after another inside
 // the workgroup, the folded cross keys / values re-requested per group (from L2 after the first).  The group count is a
@@ -205,15 +155,10 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
                     // mean and 1/sqrt(var + eps) of the row from its per-part (mean, M2) pairs (pairwise update of Chan et al.)
                     float n = 0.f, mu = 0.f, m2 = 0.f;
 #pragma unroll
-                    for (int p = 0; p < PARTS; ++p) {
-                        const float nb = 128.f, nt = n + nb, d = stp[u][p].x - mu;
-                        mu += d * (nb / nt);
-                        m2 += stp[u][p].y + d * d * (n * nb / nt);
-                        n = nt;
-                    }
-                    const float rstd = 1.0f / sqrtf(m2 / n + 1e-5f);
-                    v = make_float4((v.x - mu) * rstd * gv[u].x + bv[u].x, (v.y - mu) * rstd * gv[u].y + bv[u].y,
-                                    (v.z - mu) * rstd * gv[u].z + bv[u].z, (v.w - mu) * rstd * gv[u].w + bv[u].w);
+                    for (int p = 0; p < PARTS; ++p) chan_step(n, mu, m2, 128.f, stp[u][p].x, stp[u][p].y);
+                    const float rstd = chan_rstd(m2, n);
+                    v = make_float4(ln_apply(v.x, mu, rstd, gv[u].x, bv[u].x), ln_apply(v.y, mu, rstd, gv[u].y, bv[u].y),
+                                    ln_apply(v.z, mu, rstd, gv[u].z, bv[u].z), ln_apply(v.w, mu, rstd, gv[u].w, bv[u].w));
                 }
                 *reinterpret_cast<float4*>(xin + rr * H + c4) = v;
                 *reinterpret_cast<float4*>(qs + rr * H + c4) = make_float4(qv[u].x * scale, qv[u].y * scale, qv[u].z * scale, qv[u].w * scale);
@@ -268,11 +213,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
         __syncthreads();
         for (int rh = wave; rh < rn * HEADS; rh += NW) {
             float* row = sc + rh * SP;
-            const float v = lane < P ? row[lane] : -INFINITY;
-            const float m = wave_max(v);
-            const float e = lane < P ? expf(v - m) : 0.f;
-            const float tot = wave_sum(e);
-            if (lane < P) row[lane] = e / tot;
+            const float pr = wave_softmax(lane < P ? row[lane] : 0.f, lane < P);
+            if (lane < P) row[lane] = pr;
         }
         __syncthreads();
         // ---- self-attention output, one row at a time: this wave's share -> LDS ----
@@ -287,9 +229,13 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
                 const bool on = rr < rn && p < t;
 #pragma unroll
                 for (int h = 0; h < HEADS; ++h) {
+                    // a masked pair was loaded from a cell nothing has written yet: its bytes are selected away, not
+                    // multiplied by a zero weight (0 * NaN is NaN, and a cache need not be zero-filled)
+                    const uint4 bits = on ? __builtin_bit_cast(uint4, vreg[j][h]) : make_uint4(0u, 0u, 0u, 0u);
+                    const Vec16<T> val = __builtin_bit_cast(Vec16<T>, bits);
                     const float wgt = on ? sc[(rr * HEADS + h) * SP + p] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, to_f32<T>(vreg[j][h].v[e]), acc[e]);
+                    for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, to_f32<T>(val.v[e]), acc[e]);
                 }
             }
             if (wave == rr && rr < rn) {
@@ -345,8 +291,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
             for (int e4 = 0; e4 < VEC; e4 += 4) {
                 const float4 g1 = *reinterpret_cast<const float4*>(vecs + H + lc + e4), b1 = *reinterpret_cast<const float4*>(vecs + 2 * H + lc + e4);
                 *reinterpret_cast<float4*>(xs + rr * H + lc + e4) =
-                    make_float4(v[e4] * rstd * g1.x + b1.x, v[e4 + 1] * rstd * g1.y + b1.y, v[e4 + 2] * rstd * g1.z + b1.z,
-                                v[e4 + 3] * rstd * g1.w + b1.w);
+                    make_float4(ln_scale(v[e4], rstd, g1.x, b1.x), ln_scale(v[e4 + 1], rstd, g1.y, b1.y), ln_scale(v[e4 + 2], rstd, g1.z, b1.z),
+                                ln_scale(v[e4 + 3], rstd, g1.w, b1.w));
             }
         }
         __syncthreads();
@@ -378,11 +324,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
         __syncthreads();
         for (int rh = wave; rh < rn * HEADS; rh += NW) {
             float* row = sc + rh * SP;
-            const float v = lane < S ? row[lane] : -INFINITY;
-            const float m = wave_max(v);
-            const float e = lane < S ? expf(v - m) : 0.f;
-            const float tot = wave_sum(e);
-            if (lane < S) row[lane] = e / tot;
+            const float pr = wave_softmax(lane < S ? row[lane] : 0.f, lane < S);
+            if (lane < S) row[lane] = pr;
         }
         __syncthreads();
         if (a.attn_out) {
@@ -393,7 +336,7 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
 #pragma unroll
                 for (int hh = 0; hh < HEADS; ++hh) sum += sc[(rr * HEADS + hh) * SP + p];
                 float* dst = a.attn_out + (n0 + rr) * a.ld_attn + p;
-                *dst = (a.accumulate ? *dst : 0.f) + sum * hs;
+                *dst = __builtin_fmaf(sum, hs, a.accumulate ? *dst : 0.f);
             }
         }
 #pragma unroll
@@ -432,7 +375,7 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
             *reinterpret_cast<float2*>(a.y + (n0 + rr) * H + col) = make_float2(v0, v1);
             const float mean = wave_sum(v0 + v1) / 128.f;
             const float d0 = v0 - mean, d1 = v1 - mean;
-            const float m2 = wave_sum(d0 * d0 + d1 * d1);
+            const float m2 = wave_sum(sq_pair(d0, d1));
             if (lane == 0 && a.stats_out) {
                 float* dst = a.stats_out + ((n0 + rr) * PARTS + pp) * 2;
                 dst[0] = mean;
@@ -446,12 +389,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
 template <typename T, int RG, int HEADS, int NG> int launch_fused_attn(const FusedAttnArgs& a, hipStream_t s) {
     constexpr int H = 64 * Vec16<T>::N;
     const size_t lds = sizeof(float) * ((size_t)3 * RG * H + RG * HEADS * 64 + 8 * RG * (size_t)H + 3 * H);
-    static std::atomic<bool> granted{false};  // lanes call from several host threads
-    if (!granted) {
-        MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<T, RG, HEADS, NG>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        granted = true;
-    }
+    static std::atomic<uint64_t> granted{0};  // one bit per device; lanes call from several host threads
+    MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&attn_fused_kernel<T, RG, HEADS, NG>), 150 * 1024, granted));
     MIC_LAUNCH((attn_fused_kernel<T, RG, HEADS, NG>), dim3(a.N / a.R), dim3(512), lds, s, a);
     return 0;
 }

@@ -923,12 +923,8 @@ __global__ __launch_bounds__(256) void cross_fold_c_kernel(const T* __restrict__
 template <typename T, int RG, int HEADS, bool MULTI> int launch_cross_fold_rg(const FoldArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)a.R * a.H + RG * HEADS * 64 + 8 * RG * (size_t)a.H + 2 * a.R);
     MIC_ARG_CHECK(lds <= 150 * 1024, "mic_cross_attn_folded: %zu bytes of LDS needed", lds);
-    static std::atomic<bool> granted{false};  // lanes call from several host threads
-    if (!granted) {
-        MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_fold_kernel<T, RG, HEADS, MULTI>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        granted = true;
-    }
+    static std::atomic<uint64_t> granted{0};  // one bit per device; lanes call from several host threads
+    MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&cross_fold_kernel<T, RG, HEADS, MULTI>), 150 * 1024, granted));
     MIC_LAUNCH((cross_fold_kernel<T, RG, HEADS, MULTI>), dim3(a.N / a.R), dim3(1024), lds, s, a);
     return 0;
 }
@@ -942,12 +938,8 @@ template <typename T, int HEADS> int launch_cross_fold(const FoldArgs& a, hipStr
 
 template <typename T, int RG> int launch_cross_wide_rg(const AttnArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * (RG * (size_t)a.heads * 64 + 8 * RG * (size_t)a.H);
-    static std::atomic<bool> granted{false};  // lanes call from several host threads
-    if (!granted) {
-        MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_wide_kernel<T, RG>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        granted = true;
-    }
+    static std::atomic<uint64_t> granted{0};  // one bit per device; lanes call from several host threads
+    MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&cross_attn_wide_kernel<T, RG>), 150 * 1024, granted));
     MIC_LAUNCH((cross_attn_wide_kernel<T, RG>), dim3(a.N / a.rows_per_image), dim3(1024), lds, s, a);
     return 0;
 }

@@ -616,21 +616,41 @@ bool mic_tr_fused_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* ws
 }
 
 int mic_tr_step_impl(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
-                     int attn_mode, bool skip_embed, void* stream);
+                     int attn_mode, bool skip_embed, void* stream, bool allow_persist = false);
 
 extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
                            const int32_t* anc, int t, int attn_mode, void* stream) {
     return mic_tr_step_impl(dec, ws, tokens, ld_tok, anc, t, attn_mode, false, stream);
 }
 
+extern "C" int mic_tr_step_persistent(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
+                                      const int32_t* anc, int t, int attn_mode, void* stream) {
+    MIC_TRY(check_tr(dec, ws));
+    MIC_ARG_CHECK(mic_tr_persist_eligible(dec, ws), "mic_tr_step_persistent: this decoder / workspace cannot take the one-launch step "
+                  "(folded weights, qkvf, vfcache, stats and sync buffers, and a shape mic_tr_persist_supported accepts)");
+    return mic_tr_step_impl(dec, ws, tokens, ld_tok, anc, t, attn_mode, false, stream, true);
+}
+
+// which schedule a step on (dec, ws) takes inside the *_steps drivers: 3 one launch, 2 fused attention, 1 chained, 0 plain
+extern "C" int mic_tr_step_schedule(const mic_tr_decoder* dec, const mic_tr_workspace* ws) {
+    if (!dec || !ws) return -1;
+    if (mic_tr_persist_eligible(dec, ws)) return 3;
+    if (ws->qkvf && mic_tr_fused_eligible(dec, ws)) return 2;
+    return chain_ok(dec, ws) ? 1 : 0;
+}
+
 int mic_tr_step_impl(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
-                     int attn_mode, bool skip_embed, void* stream) {
+                     int attn_mode, bool skip_embed, void* stream, bool allow_persist) {
     MIC_TRY(check_tr(dec, ws));
     MIC_ARG_CHECK(tokens && t >= 0 && t < ws->t_cap && t < dec->pos_rows, "mic_tr_step: position %d outside t_cap=%d / table=%d", t,
                   ws->t_cap, dec->pos_rows);
     MIC_ARG_CHECK(attn_mode == 0 || ws->attn, "mic_tr_step: attention requested without a buffer");
     hipStream_t s = (hipStream_t)stream;
     const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
+    if (allow_persist && mic_tr_persist_eligible(dec, ws)) {
+        if (!skip_embed) MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
+        return mic_tr_persist_launch(dec, ws, anc, t, attn_mode, s);
+    }
     if (ws->qkvf && mic_tr_fused_eligible(dec, ws)) return tr_step_fused(dec, ws, tokens, ld_tok, anc, t, attn_mode, skip_embed, s);
     MIC_ARG_CHECK(ws->qkv && ws->o, "mic_tr_step: this shape does not take the fused-attention step and needs the qkv and o buffers");
     if (chain_ok(dec, ws)) return tr_step_chained(dec, ws, tokens, ld_tok, anc, t, attn_mode, skip_embed, s);
@@ -677,7 +697,7 @@ extern "C" int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspa
         for (int t = t0; t < t1; ++t) {
             const mic_beam_state* cur = &st[t & 1];
             const mic_beam_state* nxt = &st[(t + 1) & 1];
-            MIC_TRY(mic_tr_step_impl(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, tail && t > t0, stream));
+            MIC_TRY(mic_tr_step_impl(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, tail && t > t0, stream, true));
             if (tail) {
                 MIC_TRY(mic_beam_tail(ws->logits, dec->vocab, dec->vocab, cur, nxt, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t,
                                       ws->t_cap, eos_id, t + 1 < t1 ? dec->tok_emb : nullptr, dec->pos_emb, ws->x, ws->xt, dec->dtype, dec->H,
@@ -703,7 +723,7 @@ extern "C" int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_works
     MIC_ARG_CHECK(t0 >= 0 && t1 >= t0 && t1 + 1 <= ws->t_cap, "mic_tr_sample_steps: steps [%d,%d) do not fit t_cap=%d", t0, t1, ws->t_cap);
     auto body = [&](void* stream) -> int {
         for (int t = t0; t < t1; ++t) {
-            MIC_TRY(mic_tr_step(dec, ws, tokens, ws->t_cap, nullptr, t, want_attn ? 2 : 0, stream));
+            MIC_TRY(mic_tr_step_impl(dec, ws, tokens, ws->t_cap, nullptr, t, want_attn ? 2 : 0, false, stream, true));
             if (u)
                 MIC_TRY(mic_sample_multinomial(ws->logits, dec->vocab, ws->N, dec->vocab, inv_temp, u + (int64_t)t * ws->N, ws->top_val,
                                                ws->top_idx, stream));

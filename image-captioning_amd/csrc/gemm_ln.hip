@@ -11,6 +11,7 @@
 // The 16 activation rows are staged once through LDS; there is no barrier in the K loop, only the
 // staging barrier and the two row reductions across waves.
 #include "mic_common.h"
+#include "decode_shared.h"
 
 #include <atomic>
 
@@ -204,16 +205,10 @@ __device__ __forceinline__ void merge_row_stats(const LnRef& l, int m, float& me
     float n = 0.f, mu = 0.f, m2 = 0.f;
 #pragma unroll
     for (int p = 0; p < MAX_LN_PARTS; ++p) {
-        if (p < l.parts) {
-            const float nb = (float)min(128, l.width - 128 * p), mb = pr[p].x, sb = pr[p].y;
-            const float nt = n + nb, d = mb - mu;
-            mu += d * (nb / nt);
-            m2 += sb + d * d * (n * nb / nt);
-            n = nt;
-        }
+        if (p < l.parts) chan_step(n, mu, m2, (float)min(128, l.width - 128 * p), pr[p].x, pr[p].y);
     }
     mean = mu;
-    rstd = 1.0f / sqrtf(m2 / n + 1e-5f);
+    rstd = chan_rstd(m2, n);
 }
 
 // NWV waves share the 128 columns (8 / NWV tiles of 16 each).  A wave's weight stream is a chain of
@@ -300,10 +295,10 @@ __global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : (MT == 1 && N
                     const float4 v = *reinterpret_cast<const float4*>(src + e4);
                     const float4 g = *reinterpret_cast<const float4*>(a.xl.gamma + ch * VEC + e4);
                     const float4 b = *reinterpret_cast<const float4*>(a.xl.beta + ch * VEC + e4);
-                    o.v[e4 + 0] = from_f32<T>((v.x - mean) * rstd * g.x + b.x);
-                    o.v[e4 + 1] = from_f32<T>((v.y - mean) * rstd * g.y + b.y);
-                    o.v[e4 + 2] = from_f32<T>((v.z - mean) * rstd * g.z + b.z);
-                    o.v[e4 + 3] = from_f32<T>((v.w - mean) * rstd * g.w + b.w);
+                    o.v[e4 + 0] = from_f32<T>(ln_apply(v.x, mean, rstd, g.x, b.x));
+                    o.v[e4 + 1] = from_f32<T>(ln_apply(v.y, mean, rstd, g.y, b.y));
+                    o.v[e4 + 2] = from_f32<T>(ln_apply(v.z, mean, rstd, g.z, b.z));
+                    o.v[e4 + 3] = from_f32<T>(ln_apply(v.w, mean, rstd, g.w, b.w));
                 }
                 st16(reinterpret_cast<T*>(xs + row * xrow + ch * 16), o);
             } else {
@@ -351,7 +346,7 @@ __global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : (MT == 1 && N
                 float x = acc[i][j][e] + bv[j][e];
                 if (n + e < a.N) {
                     if (a.res) x += rv[i][j][e];
-                    if (a.rl.raw) x += (rv[i][j][e] - rs_r[i * 16 + r][0]) * rs_r[i * 16 + r][1] * gv[j][e] + bev[j][e];
+                    if (a.rl.raw) x += ln_apply(rv[i][j][e], rs_r[i * 16 + r][0], rs_r[i * 16 + r][1], gv[j][e], bev[j][e]);
                 } else {
                     x = 0.f;
                 }
@@ -439,12 +434,8 @@ template <typename T, int MT, int NWV = 4> int launch_skinny(SkinnyArgs& a, hipS
     const size_t lds = (size_t)MT * 16 * ((size_t)a.K * sizeof(T) + 16);
     MIC_ARG_CHECK(lds <= 140 * 1024, "mic_linear_skinny: K=%d needs %zu bytes of LDS", a.K, lds);
     if (lds > 48 * 1024) {
-        static std::atomic<bool> granted{false};  // lanes call from several host threads
-        if (!granted) {
-            MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<T, MT, NWV>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-            granted = true;
-        }
+        static std::atomic<uint64_t> granted{0};  // one bit per device; lanes call from several host threads
+        MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&skinny_gemm_kernel<T, MT, NWV>), 140 * 1024, granted));
     }
     a.col_blocks = (a.N + 127) / 128;
     static const int xcd_rows = [] { const char* e = getenv("MIC_SKINNY_XCD_ROWS"); return e ? atoi(e) : 1; }();
@@ -469,12 +460,8 @@ template <typename T, int NW, int TPW> int launch_gl(const GemmLnArgs& a, hipStr
     const size_t lds = 16 * ((size_t)a.K * sizeof(T) + 16);
     MIC_ARG_CHECK(lds <= 150 * 1024, "mic_linear_res_ln: K=%d needs %zu bytes of LDS", a.K, lds);
     if (lds > 48 * 1024) {
-        static std::atomic<size_t> granted{0};  // raise the dynamic-LDS limit of this variant once per size class
-        if (lds > granted) {
-            MIC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_res_ln_kernel<T, NW, TPW>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            granted = 150 * 1024;
-        }
+        static std::atomic<uint64_t> granted{0};  // one bit per device
+        MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&gemm_res_ln_kernel<T, NW, TPW>), 150 * 1024, granted));
     }
     MIC_LAUNCH((gemm_res_ln_kernel<T, NW, TPW>), dim3((a.M + 15) / 16), dim3(NW * 64), lds, s, a);
     return 0;

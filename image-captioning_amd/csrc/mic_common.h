@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "../../include/mic_hip.h"
 
 #define MIC_WAVE 64
@@ -44,6 +46,19 @@ void mic_set_error(const char* fmt, ...);
         if (rc_ != 0) return rc_; \
     } while (0)
 
+// Raising a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) applies to the current device only, so
+// the grant is remembered per (kernel, device): `mask` is the caller's static word for that kernel, one bit per device
+// ordinal (ordinals beyond 63 ask every time).  Safe from several host threads: asking twice is harmless.
+static inline int mic_grant_dynamic_lds(const void* func, int bytes, std::atomic<uint64_t>& mask) {
+    int dev = 0;
+    MIC_HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t bit = dev >= 0 && dev < 64 ? 1ull << dev : 0;
+    if (bit && (mask.load(std::memory_order_acquire) & bit)) return 0;
+    MIC_HIP_CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (bit) mask.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
 // ---- per-launch event timing shared by the GEMM-class kernels (mic_profile_begin / mic_profile_end) ----
 // open returns NULL when profiling is off, the stream is capturing or the pool is used up; slot = 2 * (tiles
 // of fewer than 128 rows) + (bf16).  close records the closing event.
@@ -63,6 +78,10 @@ struct MicProfScope {
 // ---- decoder-step internals shared between the drivers ----
 // whether a step on (dec, ws) can take the fused-attention path, the temporary ws->qkvf aside
 bool mic_tr_fused_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
+// the one-launch step (decode_persist.hip): whether (dec, ws) can take it, and the launch of the layers and the vocabulary
+// projection on the residual stream already in ws->x / ws->xt
+bool mic_tr_persist_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
+int mic_tr_persist_launch(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* anc, int t, int attn_mode, hipStream_t s);
 
 // ---- element types ----
 typedef __bf16 bf16_t;

@@ -38,6 +38,9 @@ class Lanes:
         out: List = [None] * len(items)
         errors: List = []
         n = min(len(self.models), lanes) if lanes > 0 else len(self.models)
+        for m in self.models:  # a model whose decode step can be one GPU-filling launch uses it only when alone on the GPU
+            if hasattr(m, "_concurrent"):
+                m._concurrent = n > 1 and len(items) > 1
 
         def work(lane: int):
             try:

@@ -22,7 +22,7 @@ from .vocabulary import EOS, PAD, SOS, UNK
 
 class ImageCaptioner:
     def __init__(self, vocab, num_heads: int = 2, dtype: torch.dtype = torch.bfloat16, encoder: str = "resnet50",
-                 sync_every: int = 8, use_graph: bool = True, decode_groups: int = 1):
+                 sync_every: int = 8, use_graph: bool = True, decode_groups: int = 1, persistent: bool = True):
         if encoder not in ("resnet50", "swin", "none"):
             raise ValueError(f"Encoder {encoder} not recognized")
         self.vocab = vocab
@@ -34,6 +34,12 @@ class ImageCaptioner:
         # beam search over a large batch runs as this many independent sub-batches on their own streams:
         # the per-step kernels are latency bound, so concurrent sub-batches fill the otherwise idle CUs
         self.decode_groups = max(1, int(decode_groups))
+        # one launch per decode step (mic_tr_step_persistent) where the shape allows it.  That launch wants the GPU to
+        # itself (its workgroups wait for each other), so it is not used while several searches share the device:
+        # concurrent decode groups, or lanes.Lanes with more than one batch in flight (which sets _concurrent).
+        self.persistent = bool(persistent)
+        self._concurrent = False
+        self._ws_lock = threading.Lock()
         self._side_streams = []
         self._sd = None
         self.device = None
@@ -96,7 +102,7 @@ class ImageCaptioner:
         if self.device is None:
             raise RuntimeError("lane_copy() needs a model that is on its device")
         m = copy.copy(self)
-        m._ws_cache, m._side_streams = {}, []
+        m._ws_cache, m._side_streams, m._ws_lock = {}, [], threading.Lock()
         if self.encoder is not None:
             m.encoder = copy.copy(self.encoder)
             m.encoder._ws = None
@@ -104,10 +110,13 @@ class ImageCaptioner:
 
     # ---- workspace ----------------------------------------------------------------------------
     def _workspace(self, N: int, t_cap: int, S: int, rpi: int, K: int, attn_mode: int, slot: int = 0):
-        key = (N, t_cap, S, rpi, K, attn_mode, slot)
-        hit = self._ws_cache.get(key)
-        if hit is not None:
-            return hit
+        want_persist = self.persistent and not self._concurrent and self.decode_groups == 1
+        key = (N, t_cap, S, rpi, K, attn_mode, slot, want_persist)
+        with self._ws_lock:  # decode groups and lanes call from several host threads
+            hit = self._ws_cache.pop(key, None)
+            if hit is not None:
+                self._ws_cache[key] = hit  # most recently used last
+                return hit
         d, dev, H, V, Ly = self.dtype, self.device, self.dec.H, self.dec.vocab, self.dec.layers
         f32 = torch.float32
         t = {
@@ -131,6 +140,10 @@ class ImageCaptioner:
         if fuse:  # both attentions of a layer in one launch: the cached values carry the output projection
             t["qkvf"] = torch.empty(N, (2 + heads) * H, dtype=f32, device=dev)
             t["vfc"] = torch.zeros(Ly, N, t_cap, heads, H, dtype=d, device=dev)
+        persist = fuse and want_persist and V % 4 == 0 and bool(
+            L.lib.mic_tr_persist_supported(L.dtype_code(d), H, heads, Ly, S, rpi, t_cap, N))
+        if persist:  # seam counters and the error word of the one-launch step
+            t["sync"] = torch.zeros(int(L.lib.mic_tr_persist_sync_words(N, rpi)), dtype=torch.int32, device=dev)
         if attn_mode == 1:
             t["attn"] = torch.zeros(N, t_cap, S, dtype=f32, device=dev)
         elif attn_mode == 2:
@@ -149,10 +162,37 @@ class ImageCaptioner:
                 ws.vfcache[l] = t["vfc"][l].data_ptr()
         ws.attn = t["attn"].data_ptr() if attn_mode else None
         ws.stats[0], ws.stats[1] = t["stats"][0].data_ptr(), t["stats"][1].data_ptr()
-        if len(self._ws_cache) > 4 * self.decode_groups:
-            self._ws_cache.clear()
-        self._ws_cache[key] = (ws, t)
+        ws.sync = t["sync"].data_ptr() if persist else None
+        with self._ws_lock:
+            # at most four workspaces per slot, the least recently used of THIS slot dropped first: another group's
+            # workspace may be in the middle of a search
+            mine = [k for k in self._ws_cache if k[6] == slot]
+            for k in mine[: max(0, len(mine) - 3)]:
+                del self._ws_cache[k]
+            self._ws_cache[key] = (ws, t)
         return ws, t
+
+    def step_schedule(self, ws) -> str:
+        """Name of the schedule a decode step on this workspace takes inside the search drivers."""
+        return {3: "persistent", 2: "fused14", 1: "chained", 0: "tiled"}.get(
+            int(L.lib.mic_tr_step_schedule(C.byref(self.dec), C.byref(ws))), "unknown")
+
+    def check_errors(self):
+        """Raises if a one-launch decode step of any cached workspace reported a timed-out wait (synchronises)."""
+        with self._ws_lock:
+            held = [t for _, t in self._ws_cache.values()]
+        for t in held:
+            self._check_sync(t)
+
+    @staticmethod
+    def _check_sync(t):
+        """The one-launch step reports a wait that ran out in its error word instead of hanging the GPU."""
+        if "sync" in t:
+            code = int(t["sync"][-64].item())
+            if code:
+                t["sync"].zero_()
+                raise RuntimeError(f"persistent decode step: a wait between workgroups timed out (code {code:#x}); "
+                                   "was another kernel occupying the GPU?")
 
     # ---- search -------------------------------------------------------------------------------
     def _check_feats(self, feats: torch.Tensor) -> torch.Tensor:
@@ -252,6 +292,7 @@ class ImageCaptioner:
         L.check(L.lib.mic_beam_finalize(C.byref(st[t0 & 1]), sqrt_tab.data_ptr(), B, K, t_cap, tokens.data_ptr(), lengths.data_ptr(),
                                         score.data_ptr(), t["attn"].data_ptr() if return_attn else None, S,
                                         L.ptr(attn), stream), "mic_beam_finalize")
+        self.last_schedule = self.step_schedule(ws)
 
     def sample_ids(self, feats: torch.Tensor, max_len: int, temp: Optional[float], return_attn: bool = False,
                    uniforms: Optional[torch.Tensor] = None):
@@ -297,6 +338,7 @@ class ImageCaptioner:
                 done_steps = t1 - len(lv) + lv.index(0) + 1
                 break
         attn = t["attn"][:, :done_steps].clone() if return_attn else None
+        self.last_schedule = self.step_schedule(ws)
         return tokens[:, : done_steps + 1].clone(), total.clone(), attn
 
     # ---- reference-compatible API -------------------------------------------------------------
@@ -378,6 +420,7 @@ class ImageCaptioner:
         if beam_size > 1:
             tokens, lengths, score, attn = self.beam_search_ids(feats, max_len, beam_size, return_attn)
             tok, ln = tokens.cpu().numpy(), lengths.cpu().numpy()
+            self.check_errors()
             ids = [tok[b, : ln[b]].tolist() for b in range(tok.shape[0])]
             captions = [vocab.encode_as_words(i) for i in ids]
             if not return_attn:
@@ -386,6 +429,7 @@ class ImageCaptioner:
             return captions, score, [[a[b, s] for s in range(ln[b] - 1)] for b in range(len(ids))]
         tokens, total, attn = self.sample_ids(feats, max_len, temp, return_attn, uniforms)
         captions = [vocab.encode_as_words(row) for row in tokens.cpu().numpy().tolist()]
+        self.check_errors()
         if not return_attn:
             return captions, total
         a = attn.cpu().numpy()

@@ -606,6 +606,8 @@ typedef struct mic_tr_workspace {
     float* cross_c[MIC_MAX_LAYERS];   /*           [N/rows_per_image][S][heads] fp32 */
     float* qkvf;                      /* optional, [N][(2+heads)H] fp32: packed q | k | folded values of the new position */
     void* vfcache[MIC_MAX_LAYERS];    /* optional, each [N][t_cap][heads][H] dtype: folded self-attention values */
+    uint32_t* sync;                   /* optional, mic_tr_persist_sync_words(N, rows_per_image) words, zero when first used:
+                                         seam counters and the error word of the one-launch step (mic_tr_step_persistent) */
 } mic_tr_workspace;
 
 /* Cross-attention keys/values of every layer from image tokens feats [B][S][H] (dtype):
@@ -618,6 +620,25 @@ int mic_tr_cross_kv(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const
  * anc: beam ancestry [N][t_cap] or NULL.  attn_mode: 0 none, 1 beam layout, 2 sampling layout. */
 int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
                 const int32_t* anc, int t, int attn_mode, void* stream);
+
+/* mic_tr_step (the embedding aside, every layer and the vocabulary projection) as ONE launch: the rows of a step are
+ * independent per image, so clusters of 16 workgroups (16 images each) carry their rows through every sub-layer and
+ * exchange intermediate results inside the launch (write-through stores, a per-seam arrival counter, L1-bypassing
+ * loads) instead of ending a kernel after every sub-layer.  Same arithmetic as mic_tr_step, bit for bit.  Replaces the
+ * loop body of models/transformer.py:602-609 / :492-507 like mic_tr_step.  Needs what the fused-attention step needs
+ * (folded weights, qkvf, vfcache, stats) plus ws->sync; supported shapes: mic_tr_persist_supported (one 16-byte
+ * element per lane per row, at most 2 heads, 3 rows per image, 32 cached positions, 256 images).  The launch assumes
+ * that its workgroups (one per CU, 16 per cluster) become resident together; every wait is bounded, and a wait
+ * that runs out sets the error word ws->sync[mic_tr_persist_sync_words - 64] (non-zero = seam index + 0x100) and ends
+ * the launch.  Do not run two of these launches concurrently on one GPU. */
+int mic_tr_persist_supported(int dtype, int H, int heads, int layers, int S, int rows_per_image, int t_cap, int N);
+int64_t mic_tr_persist_sync_words(int N, int rows_per_image);
+int mic_tr_step_persistent(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
+                           const int32_t* anc, int t, int attn_mode, void* stream);
+/* Which schedule a step on (dec, ws) takes inside mic_tr_beam_steps / mic_tr_sample_steps: 3 = the one-launch step,
+ * 2 = one launch per sub-layer with both attentions fused, 1 = chained skinny GEMMs, 0 = tiled GEMMs (no reference counterpart:
+ * diagnostic, so that a benchmark line can say what it timed). */
+int mic_tr_step_schedule(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
 
 /* mic_tr_step for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same step, same kernels,
