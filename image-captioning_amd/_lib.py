@@ -207,6 +207,7 @@ SIGNATURES = {
     "mic_tr_step": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mic_tr_step_persistent": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mic_tr_persist_supported": (C.c_int, [C.c_int] * 8),
+    "mic_tr_persist_trace": (C.c_int, [vp]),
     "mic_tr_step_schedule": (C.c_int, [P(TrDecoder), P(TrWorkspace)]),
     "mic_tr_persist_sync_words": (C.c_int64, [C.c_int, C.c_int]),
     "mic_tr_step_static": (C.c_int, [P(TrDecoder), P(TrWorkspace), vp, C.c_int, vp, C.c_int, C.c_int, vp]),

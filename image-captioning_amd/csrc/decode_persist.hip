@@ -127,7 +127,13 @@ struct PersistArgs {
     unsigned* sync;   // [clusters][MAX_SEAMS] seam counters, then the error word
     int N, B, R, S, t, t_cap, L, V, attn_mode, clusters;
     int stop_seam;  // diagnostic: the launch ends once this seam has been arrived at (-1: never)
+    unsigned long long* trace;  // diagnostic: [workgroup][128] 100 MHz time stamps, or null
 };
+
+// diagnostic time stamp (100 MHz counter) of one workgroup; costs one scalar read and one store when tracing is on
+__device__ __forceinline__ void stamp(unsigned long long* trace, int k) {
+    if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 128 + k] = __builtin_amdgcn_s_memrealtime();
+}
 
 // ---- seams ----------------------------------------------------------------------------------------------------
 struct Seam {
@@ -144,23 +150,31 @@ __device__ __forceinline__ void seam_arrive(const Seam& s, int idx) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(s.cnt + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// before the first handed-off load of a phase: all 16 workgroups of the cluster have arrived at seam idx
-__device__ __forceinline__ bool seam_wait(const Seam& s, int idx) {
-    if (threadIdx.x == 0) {
-        const unsigned want = s.base[idx] + CL;
-        unsigned spins = 0;
-        while ((int)(__hip_atomic_load(s.cnt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
-            if (spins > SPIN_MAX || ((spins & 4095u) == 0 && __hip_atomic_load(s.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                __hip_atomic_store(s.err, 0x100u + (unsigned)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *s.abort_flag = 1;
-                break;
+// Before the first handed-off load of a phase: all 16 workgroups of the cluster have arrived at seam idx.  In two parts,
+// so that what a phase requests ahead of its seam sits between them: seam_poll makes the workgroup's FIRST wave (alone)
+// wait for the counter, with nothing else in its memory queue (a poll is answered only after every load the wave issued
+// before it); the other waves run on and issue their requests; seam_join is the barrier at which they meet.
+__device__ __forceinline__ void seam_poll(const Seam& s, int idx, int wave) {
+    if (wave == 0 && idx >= 0) {
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned want = s.base[idx] + CL;
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(s.cnt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if (spins > SPIN_MAX || ((spins & 4095u) == 0 && __hip_atomic_load(s.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(s.err, 0x100u + (unsigned)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *s.abort_flag = 1;
+                    break;
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps this wave's loads below the poll
     }
+}
+__device__ __forceinline__ bool seam_join(const Seam& s) {
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the handed-off loads below the barrier
     return *s.abort_flag == 0;
 }
 
@@ -189,19 +203,27 @@ template <typename T> struct GemmIO {
 };
 
 // One lane's share of a tile's operands that no other workgroup produces: requested before the seam.
-template <int NK> struct GemmRegs {
-    uint4 w[NK];
+constexpr int KH = 16;  // k-tiles of weights a lane holds at a time
+struct GemmRegs {
+    uint4 w[KH];
     float bv[4], gv[4], bev[4];
 };
 
+// k-tiles [k0, k0 + 16) of this lane's weight fragments (NK: k-tiles of the whole K)
 template <typename T, int NK>
-__device__ __forceinline__ void gemm_prefetch(GemmRegs<NK>& g, const GemmIO<T>& io, int cb, int wave, int lane) {
+__device__ __forceinline__ void gemm_load_w(uint4 (&w)[KH], const GemmIO<T>& io, int cb, int wave, int lane, int k0) {
     constexpr int VEC = 16 / (int)sizeof(T);
-    const int q = lane >> 4;
     const int nb = cb * 128 + wave * 16;
     const T* wp = (const T*)io.wf + ((long long)(nb / 16) * NK * 64 + lane) * VEC;
 #pragma unroll
-    for (int kt = 0; kt < NK; ++kt) g.w[kt] = *reinterpret_cast<const uint4*>(wp + (long long)kt * 64 * VEC);
+    for (int kt = 0; kt < KH; ++kt) w[kt] = *reinterpret_cast<const uint4*>(wp + (long long)(k0 + kt) * 64 * VEC);
+}
+
+template <typename T, int NK>
+__device__ __forceinline__ void gemm_prefetch(GemmRegs& g, const GemmIO<T>& io, int cb, int wave, int lane) {
+    const int q = lane >> 4;
+    const int nb = cb * 128 + wave * 16;
+    gemm_load_w<T, NK>(g.w, io, cb, wave, lane, 0);
     const int n = nb + q * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -215,33 +237,39 @@ __device__ __forceinline__ void gemm_prefetch(GemmRegs<NK>& g, const GemmIO<T>& 
 // Row statistics of the cluster's rows (LayerNorm views) into LDS, then the rows themselves into LDS in T, K columns.
 // Every thread of the workgroup calls; ends with a barrier.
 template <typename T, int MT, int NK, int PARTS>
-__device__ __forceinline__ void gemm_stage_x(const GemmIO<T>& io, int m0, int M, unsigned char* xs, float (*rs_x)[2], float (*rs_r)[2]) {
+__device__ __forceinline__ void gemm_stage_x(const GemmIO<T>& io, int m0, int M, unsigned char* xs, float (*rs_x)[2], float (*rs_r)[2],
+                                             int wave, int lane, unsigned long long* trace, int tk) {
     constexpr int VEC = 16 / (int)sizeof(T), ROWS = MT * 16, CPR = 4 * NK, K = CPR * VEC, XROW = K * (int)sizeof(T) + 16;
     constexpr int XCH = ROWS * CPR / NT;  // 16-byte chunks per thread
     static_assert(ROWS * CPR % NT == 0, "whole chunks per thread");
-    const int tid = threadIdx.x;
+    const int tid = wave * 64 + lane;
+    // the row statistics (first 16 * MT threads) and the rows are requested together: one memory round trip for both
+    float2 px[PARTS], pr[PARTS];
     if (tid < ROWS) {
         const int mr = m0 + tid < M ? m0 + tid : M - 1;
-        float2 px[PARTS], pr[PARTS];
         if (io.x_ln) hld_stats<PARTS>(io.xstats, mr, px);
         if (io.r_ln) hld_stats<PARTS>(io.rstats, mr, pr);
-        if (io.x_ln) {
-            float n = 0.f, mu = 0.f, m2 = 0.f;
-#pragma unroll
-            for (int p = 0; p < PARTS; ++p) chan_step(n, mu, m2, 128.f, px[p].x, px[p].y);
-            rs_x[tid][0] = mu;
-            rs_x[tid][1] = chan_rstd(m2, n);
-        }
-        if (io.r_ln) {
-            float n = 0.f, mu = 0.f, m2 = 0.f;
-#pragma unroll
-            for (int p = 0; p < PARTS; ++p) chan_step(n, mu, m2, 128.f, pr[p].x, pr[p].y);
-            rs_r[tid][0] = mu;
-            rs_r[tid][1] = chan_rstd(m2, n);
-        }
     }
+    auto merge_stats = [&]() {
+        if (tid < ROWS) {
+            if (io.x_ln) {
+                float n = 0.f, mu = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p) chan_step(n, mu, m2, 128.f, px[p].x, px[p].y);
+                rs_x[tid][0] = mu;
+                rs_x[tid][1] = chan_rstd(m2, n);
+            }
+            if (io.r_ln) {
+                float n = 0.f, mu = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p) chan_step(n, mu, m2, 128.f, pr[p].x, pr[p].y);
+                rs_r[tid][0] = mu;
+                rs_r[tid][1] = chan_rstd(m2, n);
+            }
+            stamp(trace, tk);
+        }
+    };
     if (io.x_ln) {
-        // all raw rows are requested before the statistics are waited for
         float4 raw[XCH][VEC / 4];
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
@@ -250,7 +278,9 @@ __device__ __forceinline__ void gemm_stage_x(const GemmIO<T>& io, int m0, int M,
 #pragma unroll
             for (int e4 = 0; e4 < VEC / 4; ++e4) raw[i][e4] = hldf4(io.xraw, (unsigned)((mr * K + ch * VEC + e4 * 4) * 4));
         }
+        merge_stats();
         __syncthreads();
+        if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(trace, tk + 1); }
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int c = tid + i * NT, row = c / CPR, ch = c - row * CPR;
@@ -276,6 +306,7 @@ __device__ __forceinline__ void gemm_stage_x(const GemmIO<T>& io, int m0, int M,
             const int mr = m0 + row < M ? m0 + row : M - 1;
             raw[i] = hld16(io.x, (unsigned)mr * io.ld_x_b + (unsigned)ch * 16u);
         }
+        merge_stats();
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int c = tid + i * NT, row = c / CPR, ch = c - row * CPR;
@@ -283,14 +314,15 @@ __device__ __forceinline__ void gemm_stage_x(const GemmIO<T>& io, int m0, int M,
         }
     }
     __syncthreads();
+    stamp(trace, tk + 2);
 }
 
 // The MFMAs and the epilogue of one tile (MT * 16 rows x 128 columns) from staged rows and prefetched weights.
 template <typename T, int MT, int NK, bool HAND>
-__device__ __forceinline__ void gemm_tile(const GemmRegs<NK>& g, const GemmIO<T>& io, int cb, int m0, int M, const unsigned char* xs,
-                                          const float (*rs_r)[2], float (*red)[NW][48], int wave, int lane) {
+__device__ __forceinline__ void gemm_tile(const GemmRegs& g, const uint4 (&w2)[KH], const GemmIO<T>& io, int cb, int m0, int M, const unsigned char* xs,
+                                          const float (*rs_r)[2], float (*red)[NW][48], int wave, int lane, unsigned long long* trace, int tk) {
     constexpr int VEC = 16 / (int)sizeof(T), CPR = 4 * NK, K = CPR * VEC, XROW = K * (int)sizeof(T) + 16, ROWS = MT * 16;
-    const int tid = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const int tid = wave * 64 + lane, r = lane & 15, q = lane >> 4;
     const int nb = cb * 128 + wave * 16, n = nb + q * 4;
     // residual values of this lane's outputs (rows of N columns, N a multiple of 128 for a LayerNorm view)
     float4 rv[MT];
@@ -307,14 +339,26 @@ __device__ __forceinline__ void gemm_tile(const GemmRegs<NK>& g, const GemmIO<T>
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const unsigned char* xp = xs + r * XROW + q * 16;
+    static_assert(NK == KH || NK == 2 * KH, "K is 16 or 32 k-tiles");
 #pragma unroll
-    for (int kt = 0; kt < NK; ++kt) {
+    for (int kt = 0; kt < KH; ++kt) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const uint4 xf = *reinterpret_cast<const uint4*>(xp + i * 16 * XROW + kt * 64);
             PMma<T>::run(g.w[kt], xf, acc[i]);
         }
     }
+    if constexpr (NK > KH) {
+#pragma unroll
+        for (int kt = 0; kt < KH; ++kt) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint4 xf = *reinterpret_cast<const uint4*>(xp + i * 16 * XROW + (KH + kt) * 64);
+                PMma<T>::run(w2[kt], xf, acc[i]);
+            }
+        }
+    }
+    if (trace) { asm volatile("" :: "v"(acc[0][0])); stamp(trace, tk + 3); }
     float v[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -397,17 +441,24 @@ __device__ __forceinline__ void gemm_tile(const GemmRegs<NK>& g, const GemmIO<T>
 // Returns false when a wait timed out.
 template <typename T, int MT, int NK, int PARTS, bool HAND>
 __device__ __forceinline__ bool gemm_phase(const GemmIO<T>& io, const Seam& seam, int wait_idx, int j, int m0, int M, unsigned char* xs,
-                                           float (*rs_x)[2], float (*rs_r)[2], float (*red)[NW][48], int wave, int lane) {
+                                           float (*rs_x)[2], float (*rs_r)[2], float (*red)[NW][48], int wave, int lane,
+                                           unsigned long long* trace) {
     bool first = true;
     for (int cb = (j - io.shift + 2 * CL) % CL; cb < io.CB; cb += CL) {
-        GemmRegs<NK> g;
+        GemmRegs g;
+        uint4 w2[KH];  // second half of a K of 32 k-tiles: requested once the seam is passed, in flight while the rows are staged
+        if (first) seam_poll(seam, wait_idx, wave);
         gemm_prefetch<T, NK>(g, io, cb, wave, lane);
         if (first) {
-            if (wait_idx >= 0 && !seam_wait(seam, wait_idx)) return false;
-            gemm_stage_x<T, MT, NK, PARTS>(io, m0, M, xs, rs_x, rs_r);
+            if (!seam_join(seam)) return false;
+            stamp(trace, 3 * (wait_idx + 1) + 1);
+            if constexpr (NK > KH) gemm_load_w<T, NK>(w2, io, cb, wave, lane, KH);
+            gemm_stage_x<T, MT, NK, PARTS>(io, m0, M, xs, rs_x, rs_r, wave, lane, trace, 40 + 4 * (wait_idx + 1));
             first = false;
+        } else if constexpr (NK > KH) {
+            gemm_load_w<T, NK>(w2, io, cb, wave, lane, KH);
         }
-        gemm_tile<T, MT, NK, HAND>(g, io, cb, m0, M, xs, rs_r, red, wave, lane);
+        gemm_tile<T, MT, NK, HAND>(g, w2, io, cb, m0, M, xs, rs_r, red, wave, lane, trace, 40 + 4 * (wait_idx + 1));
     }
     return true;
 }
@@ -415,6 +466,7 @@ __device__ __forceinline__ bool gemm_phase(const GemmIO<T>& io, const Seam& seam
 // ---- attention phase ------------------------------------------------------------------------------------------
 template <typename T, int RG, int HEADS> struct AttnPre {
     static constexpr int PPW = 32 / NW, NJ = RG * PPW;
+    int srow[NJ];  // wave-uniform: the row whose cache holds position p of this wave's pair
     Vec16<T> kreg[NJ], vreg[NJ][HEADS];
 };
 
@@ -432,27 +484,29 @@ struct AttnIO {
 // cache rows of this wave's (row, position) pairs: ancestry, then keys and folded values.  Nothing here was written
 // by another workgroup of this launch: the cache cells of earlier positions and the ancestry table come from earlier launches.
 template <typename T, int RG, int HEADS>
-__device__ __forceinline__ void attn_prefetch(AttnPre<T, RG, HEADS>& pre, const PLayer& ly, const int32_t* anc, long long n0, int rn, int t,
-                                              int t_cap, int wave, int lane) {
-    constexpr int VEC = Vec16<T>::N, H = 64 * VEC, PPW = 32 / NW, NJ = RG * PPW;
-    const int lc = lane * VEC;
-    const T* kc = (const T*)ly.kcache;
-    const T* vc = (const T*)ly.vfcache;
-    int srow[NJ];
+__device__ __forceinline__ void attn_ancestry(AttnPre<T, RG, HEADS>& pre, const int32_t* anc, long long n0, int rn, int t, int t_cap, int wave) {
+    constexpr int PPW = 32 / NW, NJ = RG * PPW;
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         const int rr = jj / PPW, p = wave + NW * (jj % PPW);
         const int own = (int)n0 + (rr < rn ? rr : 0);
-        srow[jj] = own;
+        pre.srow[jj] = own;
         if (anc) {
             const int got = __builtin_amdgcn_readfirstlane(anc[(long long)own * t_cap + (p < t_cap ? p : 0)]);
-            srow[jj] = p < t ? got : own;  // entries at and beyond t are not ancestry yet
+            pre.srow[jj] = p < t ? got : own;  // entries at and beyond t are not ancestry yet
         }
     }
+}
+template <typename T, int RG, int HEADS>
+__device__ __forceinline__ void attn_prefetch(AttnPre<T, RG, HEADS>& pre, const PLayer& ly, int t, int t_cap, int wave, int lane) {
+    constexpr int VEC = Vec16<T>::N, H = 64 * VEC, PPW = 32 / NW, NJ = RG * PPW;
+    const int lc = lane * VEC;
+    const T* kc = (const T*)ly.kcache;
+    const T* vc = (const T*)ly.vfcache;
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         const int p = wave + NW * (jj % PPW);
-        const long long cell = (long long)srow[jj] * t_cap + (p < t ? p : 0);
+        const long long cell = (long long)pre.srow[jj] * t_cap + (p < t ? p : 0);
         pre.kreg[jj] = ld16(kc + cell * H + lc);
 #pragma unroll
         for (int h = 0; h < HEADS; ++h) pre.vreg[jj][h] = ld16(vc + (cell * HEADS + h) * H + lc);
@@ -475,7 +529,7 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
     float* sc = qs + RG * H;             // [RG][HEADS][SP]
     float* part = sc + RG * HEADS * SP;  // [NW][RG][H]
     float* vecs = part + NW * RG * H;    // [3][H]
-    const int tid = threadIdx.x, P = t + 1;
+    const int tid = wave * 64 + lane, P = t + 1;
     const int lc = lane * VEC, hl = lane / LPH;
     const float scale = sqrtf(1.0f / (float)(H / HEADS));
     const T* kfb = (const T*)ly.kf + (long long)b * S * HEADS * H;
@@ -771,8 +825,17 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
     unsigned* bases = reinterpret_cast<unsigned*>(lds + LDS_HEAD);
     unsigned char* work = lds + LDS_HEAD + LDS_BASES;
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x;
+    // Every phase derives its lane and wave numbers from a copy of the thread index the compiler cannot see through.
+    // Otherwise everything a phase computes from the thread index alone (LDS addresses of 48 fragment reads, lane offsets
+    // of every load) is loop-invariant in the loop over layers, gets hoisted in front of it and stays live through all
+    // four phases of the loop body: hundreds of registers, spilled.
+    auto who = [](int& wave, int& lane) {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        lane = t & 63;
+        wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    };
     // workgroups with equal blockIdx % 8 were observed to share an XCD: a cluster is 16 of those
     const int xl = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cluster = (slot / CL) * 8 + xl, j = slot % CL;
@@ -788,6 +851,7 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
     // this workgroup has not arrived anywhere yet, so each counter is below its base + 16
     if (tid < nseams) bases[tid] = __hip_atomic_load(seam.cnt + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~15u;
     __syncthreads();
+    stamp(a.trace, 0);
 
     const int N = a.N, R = a.R;
     const int m0 = cluster * CL * R;          // first row of the cluster
@@ -813,21 +877,32 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
     for (int l = 0; l < a.L; ++l) {
         const PLayer& ly = a.layer[l];
         {   // ---- A: packed in-projection ----
+            int wave, lane;
+            who(wave, lane);
             GemmIO<T> io{};
             view_x(io);
             io.wf = ly.qkvf_wf; io.bias = ly.qkvf_b;
             io.out = r_qkvf; io.ldc_b = (unsigned)QW * 4u; io.out_plain = a.qkvf; io.out_f32 = true; io.N = QW;
             io.CB = QW / 128; io.shift = 0;
-            if (!gemm_phase<T, RG, 16, PARTS, true>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane)) return;
+            if (!gemm_phase<T, RG, 16, PARTS, true>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane, a.trace)) return;
+            stamp(a.trace, 3 * seam_idx + 2);
             seam_arrive(seam, seam_idx++);
+            stamp(a.trace, 3 * seam_idx);
             if (seam_idx - 1 == a.stop_seam) return;
         }
         {   // ---- B: both attentions ----
             const int ns = plain ? 0 : cs ^ 1;
+            int wave, lane;
+            who(wave, lane);
             if (has_image) {
                 AttnPre<T, RG, HEADS> pre;
-                attn_prefetch<T, RG, HEADS>(pre, ly, a.anc, n0, R, a.t, a.t_cap, wave, lane);
-                if (!seam_wait(seam, seam_idx - 1)) return;
+                // the ancestry table is the previous launch's: read before the poll, so that the first wave, too, requests
+                // its cache rows the moment the seam is passed
+                attn_ancestry<T, RG, HEADS>(pre, a.anc, n0, R, a.t, a.t_cap, wave);
+                seam_poll(seam, seam_idx - 1, wave);
+                attn_prefetch<T, RG, HEADS>(pre, ly, a.t, a.t_cap, wave, lane);
+                if (!seam_join(seam)) return;
+                stamp(a.trace, 3 * seam_idx + 1);
                 AttnIO io{};
                 io.qkvf = r_qkvf; io.x_plain = plain; io.xr = plain ? r_x : r_y; io.xstats = r_st(cs); io.xg = pg; io.xb = pb;
                 io.y = r_y; io.stats_out = r_st(ns);
@@ -840,20 +915,28 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
                 attn_body<T, RG, HEADS>(pre, io, ly, b, n0, R, a.S, a.t, a.t_cap, reinterpret_cast<float*>(work), wave, lane);
             }
             plain = false; cs = ns; pg = ly.ln2_g; pb = ly.ln2_b;
+            stamp(a.trace, 3 * seam_idx + 2);
             seam_arrive(seam, seam_idx++);
+            stamp(a.trace, 3 * seam_idx);
             if (seam_idx - 1 == a.stop_seam) return;
         }
         {   // ---- C: feed-forward 1 ----
+            int wave, lane;
+            who(wave, lane);
             GemmIO<T> io{};
             view_x(io);
             io.wf = ly.ff1_wf; io.bias = ly.ff1_b;
             io.out = r_ffh; io.ldc_b = 2u * H * szT; io.out_plain = nullptr; io.out_f32 = sizeof(T) == 4; io.N = 2 * H; io.relu = 1;
             io.CB = 2 * H / 128; io.shift = 0;
-            if (!gemm_phase<T, RG, 16, PARTS, true>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane)) return;
+            if (!gemm_phase<T, RG, 16, PARTS, true>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane, a.trace)) return;
+            stamp(a.trace, 3 * seam_idx + 2);
             seam_arrive(seam, seam_idx++);
+            stamp(a.trace, 3 * seam_idx);
             if (seam_idx - 1 == a.stop_seam) return;
         }
         {   // ---- D: feed-forward 2 + residual, statistics for the next view ----
+            int wave, lane;
+            who(wave, lane);
             GemmIO<T> io{};
             io.x_ln = false; io.x = r_ffh; io.ld_x_b = 2u * H * szT;
             io.wf = ly.ff2_wf; io.bias = ly.ff2_b;
@@ -861,21 +944,28 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
             io.out = r_y; io.ldc_b = (unsigned)H * 4u; io.out_plain = a.y; io.out_f32 = true; io.N = H;
             io.want_stats = true; io.stats_out = r_st(cs ^ 1);
             io.CB = H / 128; io.shift = 2 * H / 128;  // the workgroups feed-forward 1 left idle take these tiles
-            if (!gemm_phase<T, RG, 32, PARTS, true>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane)) return;
+            if (!gemm_phase<T, RG, 32, PARTS, true>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane, a.trace)) return;
             cs ^= 1; pg = ly.ln3_g; pb = ly.ln3_b;
+            stamp(a.trace, 3 * seam_idx + 2);
             seam_arrive(seam, seam_idx++);
+            stamp(a.trace, 3 * seam_idx);
             if (seam_idx - 1 == a.stop_seam) return;
         }
     }
     {   // ---- E: vocabulary projection (read by the next launch: plain stores) ----
+        int wave, lane;
+        who(wave, lane);
         GemmIO<T> io{};
         view_x(io);
         io.wf = a.out_wf; io.bias = a.out_b;
         io.out = r_logits; io.ldc_b = (unsigned)a.V * 4u; io.out_plain = a.logits; io.out_f32 = true; io.N = a.V;
         io.CB = (a.V + 127) / 128; io.shift = 0;
-        if (!gemm_phase<T, RG, 16, PARTS, false>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane)) return;
+        if (!gemm_phase<T, RG, 16, PARTS, false>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane, a.trace)) return;
+        stamp(a.trace, 3 * seam_idx + 2);
     }
 }
+
+std::atomic<unsigned long long*> g_trace{nullptr};
 
 template <typename T, int RG, int HEADS> size_t persist_lds_bytes() {
     constexpr int VEC = Vec16<T>::N, H = 64 * VEC;
@@ -915,6 +1005,11 @@ extern "C" int mic_tr_persist_supported(int dtype, int H, int heads, int layers,
     if (N < 1 || N % rows_per_image != 0) return 0;
     const int B = N / rows_per_image;
     return (B + CL - 1) / CL <= 16;  // one workgroup per CU: at most 16 clusters of 16 on the 256 CUs
+}
+
+extern "C" int mic_tr_persist_trace(void* buffer) {
+    g_trace.store(static_cast<unsigned long long*>(buffer));
+    return 0;
 }
 
 extern "C" int64_t mic_tr_persist_sync_words(int N, int rows_per_image) {
@@ -957,6 +1052,7 @@ int mic_tr_persist_launch(const mic_tr_decoder* dec, const mic_tr_workspace* ws,
         const char* e = getenv("MIC_PERSIST_STOP");  // diagnostic runs only
         a.stop_seam = e ? atoi(e) : -1;
     }
+    a.trace = g_trace.load();
     if (dec->dtype == MIC_BF16) return dec->heads == 2 ? dispatch_persist<bf16_t, 2>(a, s) : dispatch_persist<bf16_t, 1>(a, s);
     return dec->heads == 2 ? dispatch_persist<float, 2>(a, s) : dispatch_persist<float, 1>(a, s);
 }

@@ -639,6 +639,11 @@ int mic_tr_step_persistent(const mic_tr_decoder* dec, const mic_tr_workspace* ws
  * 2 = one launch per sub-layer with both attentions fused, 1 = chained skinny GEMMs, 0 = tiled GEMMs (no reference counterpart:
  * diagnostic, so that a benchmark line can say what it timed). */
 int mic_tr_step_schedule(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
+/* Diagnostic, no reference counterpart: while `buffer` (device memory, 128 uint64 per workgroup of the launch: 512 * 128 * 8
+ * bytes cover every shape) is set, every one-launch step writes 100 MHz time stamps of its phases into it: [0] start, then
+ * per phase p: [3p+1] inputs may be read, [3p+2] outputs stored, [3p+3] arrival counted; GEMM phases also [40+4p .. 43+4p]: row statistics merged, rows loaded,
+ * rows staged, matrix products done.  NULL switches it off. */
+int mic_tr_persist_trace(void* buffer);
 
 /* mic_tr_step for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same step, same kernels,
