@@ -194,8 +194,7 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
             float v = 0.f;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v = fmaf(qp[e], to_f32<T>(knew.v[e]), v);
-#pragma unroll
-            for (int o = LPH >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            v = group_sum_down<LPH>(v);
             if ((lane & (LPH - 1)) == 0) sc[(wave * HEADS + hl) * SP + t] = v;
         }
         // folded cross keys (and their constants), requested once the self-attention keys have been consumed

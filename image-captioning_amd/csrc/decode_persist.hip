@@ -135,6 +135,12 @@ __device__ __forceinline__ void stamp(unsigned long long* trace, int k) {
     if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 128 + k] = __builtin_amdgcn_s_memrealtime();
 }
 
+// Workgroup barrier for data exchanged through LDS.  __syncthreads() would also wait for every vector-memory operation
+// the wave has in flight (its fence drains the memory counter): the weight fragments, cache rows and folded keys a phase
+// has requested ahead of time, and every write-through store, whose completion is a round trip to memory.  Here only the
+// LDS counter is waited for.  Nothing in this file hands GLOBAL memory from one wave of a workgroup to another.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- seams ----------------------------------------------------------------------------------------------------
 struct Seam {
     unsigned* cnt;    // this cluster's counters
@@ -173,7 +179,7 @@ __device__ __forceinline__ void seam_poll(const Seam& s, int idx, int wave) {
     }
 }
 __device__ __forceinline__ bool seam_join(const Seam& s) {
-    __syncthreads();
+    wg_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the handed-off loads below the barrier
     return *s.abort_flag == 0;
 }
@@ -207,6 +213,7 @@ constexpr int KH = 16;  // k-tiles of weights a lane holds at a time
 struct GemmRegs {
     uint4 w[KH];
     float bv[4], gv[4], bev[4];
+    float4 xg[2], xb[2];  // LayerNorm weight and bias of the columns this thread stages (a LayerNorm view as input)
 };
 
 // k-tiles [k0, k0 + 16) of this lane's weight fragments (NK: k-tiles of the whole K)
@@ -221,6 +228,16 @@ __device__ __forceinline__ void gemm_load_w(uint4 (&w)[KH], const GemmIO<T>& io,
 
 template <typename T, int NK>
 __device__ __forceinline__ void gemm_prefetch(GemmRegs& g, const GemmIO<T>& io, int cb, int wave, int lane) {
+    constexpr int VEC_ = 16 / (int)sizeof(T), CPR_ = 4 * NK;
+    static_assert(NT % CPR_ == 0, "a thread stages the same 16-byte column chunk of every row it handles");
+    if (io.x_ln) {
+        const int ch = (wave * 64 + lane) % CPR_;
+#pragma unroll
+        for (int e4 = 0; e4 < VEC_ / 4; ++e4) {
+            g.xg[e4] = *reinterpret_cast<const float4*>(io.xg + ch * VEC_ + e4 * 4);
+            g.xb[e4] = *reinterpret_cast<const float4*>(io.xb + ch * VEC_ + e4 * 4);
+        }
+    }
     const int q = lane >> 4;
     const int nb = cb * 128 + wave * 16;
     gemm_load_w<T, NK>(g.w, io, cb, wave, lane, 0);
@@ -237,12 +254,14 @@ __device__ __forceinline__ void gemm_prefetch(GemmRegs& g, const GemmIO<T>& io, 
 // Row statistics of the cluster's rows (LayerNorm views) into LDS, then the rows themselves into LDS in T, K columns.
 // Every thread of the workgroup calls; ends with a barrier.
 template <typename T, int MT, int NK, int PARTS>
-__device__ __forceinline__ void gemm_stage_x(const GemmIO<T>& io, int m0, int M, unsigned char* xs, float (*rs_x)[2], float (*rs_r)[2],
-                                             int wave, int lane, unsigned long long* trace, int tk) {
+__device__ __forceinline__ void gemm_stage_x(const GemmRegs& g, const GemmIO<T>& io, int m0, int M, unsigned char* xs, float (*rs_x)[2],
+                                             float (*rs_r)[2], int wave, int lane, unsigned long long* trace, int tk) {
     constexpr int VEC = 16 / (int)sizeof(T), ROWS = MT * 16, CPR = 4 * NK, K = CPR * VEC, XROW = K * (int)sizeof(T) + 16;
     constexpr int XCH = ROWS * CPR / NT;  // 16-byte chunks per thread
-    static_assert(ROWS * CPR % NT == 0, "whole chunks per thread");
+    constexpr int RSTEP = NT / CPR;       // rows between two chunks of a thread
+    static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "whole chunks per thread, one column chunk per thread");
     const int tid = wave * 64 + lane;
+    const int ch = tid % CPR, row0 = tid / CPR;
     // the row statistics (first 16 * MT threads) and the rows are requested together: one memory round trip for both
     float2 px[PARTS], pr[PARTS];
     if (tid < ROWS) {
@@ -273,28 +292,27 @@ __device__ __forceinline__ void gemm_stage_x(const GemmIO<T>& io, int m0, int M,
         float4 raw[XCH][VEC / 4];
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int c = tid + i * NT, row = c / CPR, ch = c - row * CPR;
+            const int row = row0 + i * RSTEP;
             const int mr = m0 + row < M ? m0 + row : M - 1;
 #pragma unroll
             for (int e4 = 0; e4 < VEC / 4; ++e4) raw[i][e4] = hldf4(io.xraw, (unsigned)((mr * K + ch * VEC + e4 * 4) * 4));
         }
         merge_stats();
-        __syncthreads();
+        wg_barrier();
         if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(trace, tk + 1); }
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int c = tid + i * NT, row = c / CPR, ch = c - row * CPR;
+            const int row = row0 + i * RSTEP;
             const float mean = rs_x[row][0], rstd = rs_x[row][1];
             Vec16<T> o;
 #pragma unroll
             for (int e4 = 0; e4 < VEC / 4; ++e4) {
                 const float4 v = raw[i][e4];
-                const float4 g = *reinterpret_cast<const float4*>(io.xg + ch * VEC + e4 * 4);
-                const float4 b = *reinterpret_cast<const float4*>(io.xb + ch * VEC + e4 * 4);
-                o.v[e4 * 4 + 0] = from_f32<T>(ln_apply(v.x, mean, rstd, g.x, b.x));
-                o.v[e4 * 4 + 1] = from_f32<T>(ln_apply(v.y, mean, rstd, g.y, b.y));
-                o.v[e4 * 4 + 2] = from_f32<T>(ln_apply(v.z, mean, rstd, g.z, b.z));
-                o.v[e4 * 4 + 3] = from_f32<T>(ln_apply(v.w, mean, rstd, g.w, b.w));
+                const float4 gg = g.xg[e4], b = g.xb[e4];
+                o.v[e4 * 4 + 0] = from_f32<T>(ln_apply(v.x, mean, rstd, gg.x, b.x));
+                o.v[e4 * 4 + 1] = from_f32<T>(ln_apply(v.y, mean, rstd, gg.y, b.y));
+                o.v[e4 * 4 + 2] = from_f32<T>(ln_apply(v.z, mean, rstd, gg.z, b.z));
+                o.v[e4 * 4 + 3] = from_f32<T>(ln_apply(v.w, mean, rstd, gg.w, b.w));
             }
             st16(reinterpret_cast<T*>(xs + row * XROW + ch * 16), o);
         }
@@ -302,18 +320,18 @@ __device__ __forceinline__ void gemm_stage_x(const GemmIO<T>& io, int m0, int M,
         uint4 raw[XCH];
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int c = tid + i * NT, row = c / CPR, ch = c - row * CPR;
+            const int row = row0 + i * RSTEP;
             const int mr = m0 + row < M ? m0 + row : M - 1;
             raw[i] = hld16(io.x, (unsigned)mr * io.ld_x_b + (unsigned)ch * 16u);
         }
         merge_stats();
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int c = tid + i * NT, row = c / CPR, ch = c - row * CPR;
+            const int row = row0 + i * RSTEP;
             *reinterpret_cast<uint4*>(xs + row * XROW + ch * 16) = raw[i];
         }
     }
-    __syncthreads();
+    wg_barrier();
     stamp(trace, tk + 2);
 }
 
@@ -340,24 +358,27 @@ __device__ __forceinline__ void gemm_tile(const GemmRegs& g, const uint4 (&w2)[K
     for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const unsigned char* xp = xs + r * XROW + q * 16;
     static_assert(NK == KH || NK == 2 * KH, "K is 16 or 32 k-tiles");
+    // The fragment reads of four k-tiles are issued together, ahead of their MFMAs (left to itself the compiler, short
+    // of registers, waits for every read right before the one MFMA that takes it).
+    constexpr int KG = 4;
+    auto mma_half = [&](const uint4 (&w)[KH], int kbase) {
 #pragma unroll
-    for (int kt = 0; kt < KH; ++kt) {
+        for (int k0 = 0; k0 < KH; k0 += KG) {
+            uint4 xf[KG][MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const uint4 xf = *reinterpret_cast<const uint4*>(xp + i * 16 * XROW + kt * 64);
-            PMma<T>::run(g.w[kt], xf, acc[i]);
+            for (int u = 0; u < KG; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xf[u][i] = *reinterpret_cast<const uint4*>(xp + i * 16 * XROW + (kbase + k0 + u) * 64);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < KG; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) PMma<T>::run(w[k0 + u], xf[u][i], acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    }
-    if constexpr (NK > KH) {
-#pragma unroll
-        for (int kt = 0; kt < KH; ++kt) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const uint4 xf = *reinterpret_cast<const uint4*>(xp + i * 16 * XROW + (KH + kt) * 64);
-                PMma<T>::run(w2[kt], xf, acc[i]);
-            }
-        }
-    }
+    };
+    mma_half(g.w, 0);
+    if constexpr (NK > KH) mma_half(w2, KH);
     if (trace) { asm volatile("" :: "v"(acc[0][0])); stamp(trace, tk + 3); }
     float v[MT][4];
 #pragma unroll
@@ -374,17 +395,18 @@ __device__ __forceinline__ void gemm_tile(const GemmRegs& g, const uint4 (&w2)[K
             v[i][e] = io.relu ? fmaxf(x, 0.f) : x;
         }
     }
+    if (trace) { asm volatile("" :: "v"(v[0][0])); stamp(trace, tk + 4); }
     if (io.want_stats) {
         // per row: mean and centred sum of squares over this workgroup's 128 columns (valid ones)
         const float cnt = (float)min(128, io.N - cb * 128);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float s = (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
+            s = sum_xor16(s);
+            s = sum_xor32(s);
             if (q == 0) red[0][wave][i * 16 + r] = s;
         }
-        __syncthreads();
+        wg_barrier();
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = i * 16 + r;
@@ -398,19 +420,23 @@ __device__ __forceinline__ void gemm_tile(const GemmRegs& g, const uint4 (&w2)[K
                 const float d = n + e < io.N ? v[i][e] - mean : 0.f;
                 sq = fmaf(d, d, sq);
             }
-            sq += __shfl_xor(sq, 16, 64);
-            sq += __shfl_xor(sq, 32, 64);
+            sq = sum_xor16(sq);
+            sq = sum_xor32(sq);
             if (q == 0) red[1][wave][row] = sq;
         }
-        __syncthreads();
+        wg_barrier();
+        float st_mean = 0.f, st_m2 = 0.f;
         if (tid < ROWS && m0 + tid < M) {
             float rsum = 0.f, m2 = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < NW; ++w8) { rsum += red[0][w8][tid]; m2 += red[1][w8][tid]; }
-            const float mean = rsum / cnt;
-            hst8<HAND>(io.stats_out, (unsigned)(((m0 + tid) * io.CB + cb) * 8), make_uint2(__builtin_bit_cast(unsigned, mean), __builtin_bit_cast(unsigned, m2)));
+            st_mean = rsum / cnt;
+            st_m2 = m2;
         }
-        __syncthreads();  // the scratch is free for the workgroup's next tile
+        wg_barrier();  // the scratch is free for the workgroup's next tile
+        if (tid < ROWS && m0 + tid < M)
+            hst8<HAND>(io.stats_out, (unsigned)(((m0 + tid) * io.CB + cb) * 8), make_uint2(__builtin_bit_cast(unsigned, st_mean), __builtin_bit_cast(unsigned, st_m2)));
+        stamp(trace, tk + 5);
     }
     if (n < io.N) {
 #pragma unroll
@@ -453,14 +479,26 @@ __device__ __forceinline__ bool gemm_phase(const GemmIO<T>& io, const Seam& seam
             if (!seam_join(seam)) return false;
             stamp(trace, 3 * (wait_idx + 1) + 1);
             if constexpr (NK > KH) gemm_load_w<T, NK>(w2, io, cb, wave, lane, KH);
-            gemm_stage_x<T, MT, NK, PARTS>(io, m0, M, xs, rs_x, rs_r, wave, lane, trace, 40 + 4 * (wait_idx + 1));
+            gemm_stage_x<T, MT, NK, PARTS>(g, io, m0, M, xs, rs_x, rs_r, wave, lane, trace, 40 + 6 * (wait_idx + 1));
             first = false;
         } else if constexpr (NK > KH) {
             gemm_load_w<T, NK>(w2, io, cb, wave, lane, KH);
         }
-        gemm_tile<T, MT, NK, HAND>(g, w2, io, cb, m0, M, xs, rs_r, red, wave, lane, trace, 40 + 4 * (wait_idx + 1));
+        gemm_tile<T, MT, NK, HAND>(g, w2, io, cb, m0, M, xs, rs_r, red, wave, lane, trace, 40 + 6 * (wait_idx + 1));
     }
     return true;
+}
+
+// A 16-byte load of data that is read once per step and never again before most of the caches have turned over (the
+// self-attention cache rows, the folded cross keys / values): flagged non-temporal when MIC_PERSIST_NT is set at build time.
+template <typename T> __device__ __forceinline__ Vec16<T> ld16s(const T* p) {
+#ifdef MIC_PERSIST_NT
+    typedef unsigned v4u_nt __attribute__((ext_vector_type(4)));
+    const v4u_nt r = __builtin_nontemporal_load(reinterpret_cast<const v4u_nt*>(p));
+    return __builtin_bit_cast(Vec16<T>, r);
+#else
+    return ld16(p);
+#endif
 }
 
 // ---- attention phase ------------------------------------------------------------------------------------------
@@ -507,9 +545,9 @@ __device__ __forceinline__ void attn_prefetch(AttnPre<T, RG, HEADS>& pre, const 
     for (int jj = 0; jj < NJ; ++jj) {
         const int p = wave + NW * (jj % PPW);
         const long long cell = (long long)pre.srow[jj] * t_cap + (p < t ? p : 0);
-        pre.kreg[jj] = ld16(kc + cell * H + lc);
+        pre.kreg[jj] = ld16s(kc + cell * H + lc);
 #pragma unroll
-        for (int h = 0; h < HEADS; ++h) pre.vreg[jj][h] = ld16(vc + (cell * HEADS + h) * H + lc);
+        for (int h = 0; h < HEADS; ++h) pre.vreg[jj][h] = ld16s(vc + (cell * HEADS + h) * H + lc);
     }
 }
 
@@ -595,7 +633,7 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
             *reinterpret_cast<float4*>(qs + rr * H + c4) = make_float4(qv[u].x * scale, qv[u].y * scale, qv[u].z * scale, qv[u].w * scale);
         }
     }
-    __syncthreads();
+    wg_barrier();
     // ---- self-attention scores ----
     {
         float pv[NJP];
@@ -624,8 +662,7 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
         float v = 0.f;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v = fmaf(qp[e], to_f32<T>(knew.v[e]), v);
-#pragma unroll
-        for (int o = LPH >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        v = group_sum_down<LPH>(v);
         if ((lane & (LPH - 1)) == 0) sc[(wave * HEADS + hl) * SP + t] = v;
     }
     // folded cross keys (and their constants), requested once the self-attention keys have been consumed
@@ -636,17 +673,17 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
         const int p = wave + NW * i, pc = p < S ? p : S - 1;  // tokens past S: a valid row, masked when used
 #pragma unroll
         for (int h = 0; h < HEADS; ++h) {
-            kx[i][h] = ld16(kfb + (pc * HEADS + h) * H + lc);
+            kx[i][h] = ld16s(kfb + (pc * HEADS + h) * H + lc);
             cx[i][h] = ly.c[((long long)b * S + pc) * HEADS + h];
         }
     }
-    __syncthreads();
+    wg_barrier();
     for (int rh = wave; rh < rn * HEADS; rh += NW) {
         float* row = sc + rh * SP;
         const float pr = wave_softmax(lane < P ? row[lane] : 0.f, lane < P);
         if (lane < P) row[lane] = pr;
     }
-    __syncthreads();
+    wg_barrier();
     // ---- self-attention output, one row at a time: this wave's share -> LDS ----
 #pragma unroll
     for (int rr = 0; rr < RG; ++rr) {
@@ -685,9 +722,9 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
     for (int i = 0; i < NI; ++i) {
         const int p = wave + NW * i, pc = p < S ? p : S - 1;
 #pragma unroll
-        for (int h = 0; h < HEADS; ++h) vx[i][h] = ld16(vfb + (pc * HEADS + h) * H + lc);
+        for (int h = 0; h < HEADS; ++h) vx[i][h] = ld16s(vfb + (pc * HEADS + h) * H + lc);
     }
-    __syncthreads();
+    wg_barrier();
     // ---- y1 = x + attention + b', u = LayerNorm1(y1): one wave per row ----
     if (wave < rn) {
         const int rr = wave;
@@ -723,7 +760,7 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
                             ln_scale(v[e4 + 3], rstd, g1.w, b1.w));
         }
     }
-    __syncthreads();
+    wg_barrier();
     // ---- cross-attention scores u . K'_h[s] + c_h[s], one row at a time ----
 #pragma unroll
     for (int rr = 0; rr < RG; ++rr) {
@@ -749,13 +786,13 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
         const int p = wave + NW * (x / HEADS);
         if (writer && rr < rn && p < S) sc[(rr * HEADS + x % HEADS) * SP + p] = pv[0];
     }
-    __syncthreads();
+    wg_barrier();
     for (int rh = wave; rh < rn * HEADS; rh += NW) {
         float* row = sc + rh * SP;
         const float pr = wave_softmax(lane < S ? row[lane] : 0.f, lane < S);
         if (lane < S) row[lane] = pr;
     }
-    __syncthreads();
+    wg_barrier();
     if (io.attn_out) {
         const float hs = io.attn_scale / (float)HEADS;
         for (int i = tid; i < rn * S; i += NT) {
@@ -786,7 +823,7 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
         for (int e4 = 0; e4 < VEC; e4 += 4)
             *reinterpret_cast<float4*>(part + (wave * RG + rr) * H + lc + e4) = make_float4(acc[e4], acc[e4 + 1], acc[e4 + 2], acc[e4 + 3]);
     }
-    __syncthreads();
+    wg_barrier();
     // ---- y2 = u + attention + b_o and its statistics per 128 columns: one wave per (row, part), 2 columns per lane ----
     for (int pair = wave; pair < rn * PARTS; pair += NW) {
         const int rr = pair / PARTS, pp = pair - rr * PARTS;
@@ -850,7 +887,7 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
     if (tid == 0) *abort_flag = 0;
     // this workgroup has not arrived anywhere yet, so each counter is below its base + 16
     if (tid < nseams) bases[tid] = __hip_atomic_load(seam.cnt + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~15u;
-    __syncthreads();
+    wg_barrier();
     stamp(a.trace, 0);
 
     const int N = a.N, R = a.R;

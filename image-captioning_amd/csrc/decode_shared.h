@@ -31,11 +31,39 @@ __device__ __forceinline__ float sq_pair(float d0, float d1) {
 
 // v of the lane whose number differs in bit O.  Within a row of 16 lanes this is a data-parallel-primitive move of the
 // vector ALU (quad permutes for 1 and 2, a rotation by 8 within the row for 8); the others go through the LDS crossbar.
+// Exchanges across rows of 16 lanes on the vector ALU as well: v_permlane16_swap trades the odd rows of one register with
+// the even rows of another, v_permlane32_swap the upper half of one with the lower half of another; with the same value in
+// both, one result holds every pair's even-row (lower-half) value and the other its odd-row (upper-half) value.
 template <int O> __device__ __forceinline__ float lane_xor(float v) {
     if constexpr (O == 1) return MIC_DPP_F32(v, 0xB1);        // quad_perm [1,0,3,2]
     else if constexpr (O == 2) return MIC_DPP_F32(v, 0x4E);   // quad_perm [2,3,0,1]
     else if constexpr (O == 8) return MIC_DPP_F32(v, 0x128);  // row_ror:8
-    else return __shfl_xor(v, O, 64);
+    else if constexpr (O == 16 || O == 32) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if constexpr (O == 16) {
+            const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            return __builtin_bit_cast(float, (lane & 16u) ? r[0] : r[1]);
+        } else {
+            const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            return __builtin_bit_cast(float, (lane & 32u) ? r[0] : r[1]);
+        }
+    } else return __shfl_xor(v, O, 64);
+}
+// v + the value of the lane 16 (32) away.  Written through lane_xor: adding the two results of one swap of a register
+// with itself comes out wrong with hipcc 7.2 (2 * v; tools/permlane_check.hip), selecting one of them does not.
+__device__ __forceinline__ float sum_xor16(float v) { return v + lane_xor<16>(v); }
+__device__ __forceinline__ float sum_xor32(float v) { return v + lane_xor<32>(v); }
+// v summed over the lanes of an aligned group of W lanes (W a power of two up to 64); every lane of the group returns the sum.
+// The order of the additions is that of a butterfly from the widest exchange down.
+template <int W> __device__ __forceinline__ float group_sum_down(float v) {
+    if constexpr (W >= 64) v += lane_xor<32>(v);
+    if constexpr (W >= 32) v += lane_xor<16>(v);
+    if constexpr (W >= 16) v += lane_xor<8>(v);
+    if constexpr (W >= 8) v += lane_xor<4>(v);
+    if constexpr (W >= 4) v += lane_xor<2>(v);
+    if constexpr (W >= 2) v += lane_xor<1>(v);
+    return v;
 }
 
 // One halving step over lane bit O: a lane keeps HALF of its 2 * HALF values and hands the other half to its partner.

@@ -116,8 +116,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_res_ln_kernel(const GemmLnArgs a
         v[j][3] = acc[j][3] + b.w + rs.w;
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
     }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = sum_xor16(s);
+    s = sum_xor32(s);
     if (q == 0) red[0][wave][r] = s;
     __syncthreads();
     float tot = 0.f;
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_res_ln_kernel(const GemmLnArgs a
             v[j][e] -= mean;
             sq = fmaf(v[j][e], v[j][e], sq);
         }
-    sq += __shfl_xor(sq, 16, 64);
-    sq += __shfl_xor(sq, 32, 64);
+    sq = sum_xor16(sq);
+    sq = sum_xor32(sq);
     if (q == 0) red[1][wave][r] = sq;
     __syncthreads();
     float var = 0.f;
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : (MT == 1 && N
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) s += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
+            s = sum_xor16(s);
+            s = sum_xor32(s);
             if (q == 0) red[0][wave][i * 16 + r] = s;
         }
         __syncthreads();
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : (MT == 1 && N
                     sq = fmaf(d, d, sq);
                 }
             }
-            sq += __shfl_xor(sq, 16, 64);
-            sq += __shfl_xor(sq, 32, 64);
+            sq = sum_xor16(sq);
+            sq = sum_xor32(sq);
             if (q == 0) red[1][wave][row] = sq;
         }
         __syncthreads();

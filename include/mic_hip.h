@@ -641,8 +641,8 @@ int mic_tr_step_persistent(const mic_tr_decoder* dec, const mic_tr_workspace* ws
 int mic_tr_step_schedule(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
 /* Diagnostic, no reference counterpart: while `buffer` (device memory, 128 uint64 per workgroup of the launch: 512 * 128 * 8
  * bytes cover every shape) is set, every one-launch step writes 100 MHz time stamps of its phases into it: [0] start, then
- * per phase p: [3p+1] inputs may be read, [3p+2] outputs stored, [3p+3] arrival counted; GEMM phases also [40+4p .. 43+4p]: row statistics merged, rows loaded,
- * rows staged, matrix products done.  NULL switches it off. */
+ * per phase p: [3p+1] inputs may be read, [3p+2] outputs stored, [3p+3] arrival counted; GEMM phases also [40+6p .. 45+6p]: row statistics merged, rows loaded,
+ * rows staged, matrix products done, epilogue values ready, output statistics stored.  NULL switches it off. */
 int mic_tr_persist_trace(void* buffer);
 
 /* mic_tr_step for callers that cannot allocate device memory (code under HIP graph capture, tight serving

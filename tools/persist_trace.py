@@ -44,15 +44,15 @@ def main():
         allarr = arr[arr > 0] - t0 if p < len(names) - 1 else torch.tensor([0.0])
         print(f"{name:14s} {int(act.sum()):6d} {r.mean():9.2f}/{r.max():8.2f} {work.mean():10.2f} {work.max():9.2f} {d.max():9.2f} {allarr.max():10.2f}")
     print(f"kernel span: {(tr[:, 1:40].max() - t0):.2f} us")
-    print("inside the GEMM phases, microseconds after 'ready' (mean over active workgroups): stats merged, rows loaded, rows staged, products done, outputs stored")
+    print("inside the GEMM phases, microseconds after 'ready' (mean over active workgroups): stats merged, rows loaded, rows staged, products done, epilogue values, statistics, outputs stored")
     for p, name in enumerate(names):
         if "attention" in name:
             continue
         ready, done = tr[:, 3 * p + 1], tr[:, 3 * p + 2]
         act = ready > 0
         parts = []
-        for k in range(4):
-            v = tr[:, 40 + 4 * p + k]
+        for k in range(6):
+            v = tr[:, 40 + 6 * p + k]
             ok = act & (v > 0)
             parts.append(f"{(v - ready)[ok].mean():6.2f}" if ok.any() else "     -")
         parts.append(f"{(done - ready)[act].mean():6.2f}")
