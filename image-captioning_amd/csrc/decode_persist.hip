@@ -475,10 +475,10 @@ __device__ __forceinline__ bool gemm_phase(const GemmIO<T>& io, const Seam& seam
         uint4 w2[KH];  // second half of a K of 32 k-tiles: requested once the seam is passed, in flight while the rows are staged
         if (first) seam_poll(seam, wait_idx, wave);
         gemm_prefetch<T, NK>(g, io, cb, wave, lane);
+        if constexpr (NK > KH) { if (first) gemm_load_w<T, NK>(w2, io, cb, wave, lane, KH); }
         if (first) {
             if (!seam_join(seam)) return false;
             stamp(trace, 3 * (wait_idx + 1) + 1);
-            if constexpr (NK > KH) gemm_load_w<T, NK>(w2, io, cb, wave, lane, KH);
             gemm_stage_x<T, MT, NK, PARTS>(g, io, m0, M, xs, rs_x, rs_r, wave, lane, trace, 40 + 6 * (wait_idx + 1));
             first = false;
         } else if constexpr (NK > KH) {
