@@ -124,6 +124,20 @@ def decode_roofline(ms: float, batch: int, beam: int, steps: int, S: int):
             "traffic_model": int(folded_total)}
 
 
+def lstm_decode_roofline(ms: float, batch: int, beam: int, steps: int, layers: int = 2):
+    """Algorithmic bytes of one LSTM beam search at bf16 over `steps` executed steps, N = batch*beam rows: per step the
+    packed [W_ih | W_hh] of every layer ((in + H) x 4H, E = H) and the vocabulary matrix once; per row the layer input
+    [x | h] read, the four gates written and read in fp32, the cell state read and written in fp32, the new hidden state
+    written; logits written and read in fp32."""
+    N, e = batch * beam, 2
+    weights = (layers * 2 * H * 4 * H + V * H) * e
+    rows = layers * N * (2 * H * e + 2 * 4 * H * 4 + 2 * H * 4 + H * e) + 2 * N * V * 4
+    total = steps * (weights + rows)
+    tbs = total / (ms * 1e-3) / 1e12
+    return {"bound": "hbm", "phase": "initial state + beam steps + best-beam extraction", "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS,
+            "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4), "ms": round(ms, 3), "algorithmic_bytes": int(total)}
+
+
 def measured_traffic():
     """HBM bytes per launch of the 128-row-tile bf16 igemm kernels on this workload, from the committed
     rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs of this script; a live
@@ -176,10 +190,13 @@ def run_job(args, amd, D, model, sd, dev, rank, world, wl):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        pre = min(1024, n)
+        # the prefix lies inside rank 0's shard and ends on a micro-batch boundary, so that the recomputation below sees
+        # the same micro-batches as the job did (tile choices depend on the batch size; bf16 bits on the tile choice)
+        lo, hi = D.shard_range(n, 0, world)
+        pre = min(1024, hi - lo)
+        pre = pre // mb * mb if pre >= mb else pre
         ref = [caption(model, make_batch(lo, min(pre, lo + mb))) for lo in range(0, pre, mb)]
         same = all(torch.equal(torch.cat([r[i] for r in ref]), x[:pre]) for i, x in enumerate((tokens, lengths, score)))
-        lo, hi = D.shard_range(n, 0, world)
         steps = (hi - lo + mb - 1) // mb
         weights = torch.arange(1, t_cap + 1, device=dev, dtype=torch.int64)
         res = {
@@ -329,17 +346,28 @@ def main():
         L.check(L.lib.mic_profile_end(c1, m1, f1), "mic_profile_end")
         single = (c1[1], m1[1], f1[1], single_ms)
 
-    decode = None
-    if rank == 0 and args.workload == "transformer":  # the byte count below is that of the folded, chained decode path
-        # the search alone (cross-K/V + beam steps + best-beam extraction) between two events on the launch
-        # stream, outside the timed region, priced against HBM bandwidth by its algorithmic bytes
-        feats = model.encode(images)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    decode, schedule = None, None
+    if rank == 0 and args.workload != "basic":
+        # the search alone (cross-K/V or initial state + beam steps + best-beam extraction) between two events on the
+        # launch stream, outside the timed region and with the GPU to itself like the timed region's batches, priced
+        # against HBM bandwidth by its algorithmic bytes
+        lstm = args.workload == "lstm"
+        feats = model.encoder(images) if lstm else model.encode(images)
         model.beam_search_ids(feats, MAX_LEN, beam)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record()
+        for _ in range(reps):
+            model.beam_search_ids(feats, MAX_LEN, beam)
         e1.record()
         torch.cuda.synchronize()
-        decode = decode_roofline(e0.elapsed_time(e1), B, beam, executed_steps, feats.shape[1])
+        d_ms = e0.elapsed_time(e1) / reps
+        decode = lstm_decode_roofline(d_ms, B, beam, executed_steps) if lstm else decode_roofline(d_ms, B, beam, executed_steps, feats.shape[1])
+        if not lstm:
+            schedule = model.last_schedule
+            decode["step_schedule"] = schedule
+    if hasattr(model, "check_errors"):
+        model.check_errors()  # raises if a workgroup of a one-launch decode step gave up waiting for another
 
     if rank == 0:
         # dominant kernel: igemm_kernel<bf16> with tiles of 128 rows and more (slot 1), the encoder's implicit-GEMM convolutions
@@ -361,17 +389,21 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.workload == "basic" else "bf16", "data": "synthetic",
             "config": {"workload": wl["label"] if B == wl["batch"] else wl["label"].replace(f"batch {wl['batch']}", f"batch {B}"),
                        "images_per_gpu_per_step": B, "executed_decode_steps": executed_steps, "parallelism": f"dp{world}",
-                       "lanes_per_gpu": n_lanes},
+                       "lanes_per_gpu": n_lanes, "decode_step_schedule": schedule},
             "roofline": {"bound": "mfma", "kernel": ("igemm_kernel<f32>" if ks == 0 else "igemm_kernel<bf16>, fused_block_kernel and stem_pool_kernel") +
-                         " (the encoder's convolution launches with tiles of 128 rows and more)", "achieved": round(achieved, 2),
+                         " (every launch of the encoder trunk and of the cross-K/V projection: one measurement scope around "
+                         "each, whatever the tile shape)", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic if args.workload == "transformer" and B == BATCH else None,
                          "traffic_unit": f"bytes/launch (rocprofv3 PMC, profiles/{traffic_file})",
                          "launches_per_step": k_n // max(1, args.steps),
                          "avg_launch_us": round(k_ms / k_n * 1e3, 2) if k_n else None,
                          "gflop_per_launch": round(k_fl / k_n / 1e9, 3) if k_n else None,
-                         "other_gemm_launches": {"igemm<bf16,64-row tiles>": {"n": cnt[3], "ms": round(ms[3], 3), "tflops": round(fl[3] / (ms[3] * 1e-3) / 1e12, 2) if ms[3] else None}}},
+                         },
         }
+        if cnt[3]:  # GEMM launches outside the measurement scopes (inside a scope every launch counts towards the scope)
+            res["roofline"]["other_gemm_launches"] = {"igemm<bf16,64-row tiles>": {"n": cnt[3], "ms": round(ms[3], 3),
+                                                      "tflops": round(fl[3] / (ms[3] * 1e-3) / 1e12, 2) if ms[3] else None}}
         if single is not None:
             res["roofline"]["note"] = (f"launch durations in the timed region, {n_lanes} batches in flight: a launch shares the GPU with "
                                        "the other lanes' kernels; roofline_single_lane is the same kernel with the GPU to itself")

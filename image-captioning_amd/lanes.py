@@ -63,6 +63,9 @@ class Lanes:
                 t.start()
             for t in threads:
                 t.join()
+        for m in self.models:  # every lane's stream is idle again: a call outside map has the GPU to itself
+            if hasattr(m, "_concurrent"):
+                m._concurrent = False
         if errors:
             raise errors[0]
         return out
