@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ("ldc", i32), ("ld_res", i32), ("relu", i32), ("k_valid", i32),
                 ("in2", vp), ("in2_img_stride", i64), ("in2_row_stride", i64),
                 ("in2_pix_stride", i32), ("stride2", i32), ("K2", i32), ("w_rows", i32),
-                ("ln_gamma", vp), ("ln_beta", vp), ("ln_out", vp), ("ld_ln_out", i32)]
+                ("ln_gamma", vp), ("ln_beta", vp), ("ln_out", vp), ("ld_ln_out", i32),
+                ("scratch", vp), ("scratch_bytes", i64)]
 
 
 class FusedBlockDesc(C.Structure):
@@ -151,6 +152,7 @@ SIGNATURES = {
     "mic_conv2d": (C.c_int, [P(ConvDesc), vp]),
     "mic_conv2d_variant": (C.c_int, [P(ConvDesc), C.c_int, vp]),
     "mic_conv2d_ln_supported": (C.c_int, [C.c_int]),
+    "mic_conv2d_scratch_bytes": (C.c_int64, []),
     "mic_bottleneck_fused_shortcut_supported": (C.c_int, [C.c_int] * 4),
     "mic_stem_pool_supported": (C.c_int, [C.c_int]),
     "mic_stem_pool": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 7 + [vp]),

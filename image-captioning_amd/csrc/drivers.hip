@@ -131,6 +131,10 @@ int linear(int dtype, const void* x, int ld_in, int M, int K, const void* w, con
 }
 
 // fused conv layer on a dense NHWC tensor [B][IH][IW][cin]
+// scratch of the launches of the forward pass under way on this thread (split-K convolutions; mic_conv_desc::scratch)
+thread_local void* t_conv_scratch = nullptr;
+thread_local int64_t t_conv_scratch_bytes = 0;
+
 int conv_layer(int dtype, const mic_conv_layer& L, const void* in, int B, int IH, int IW, const void* res, void* out, int* OHo,
                int* OWo, hipStream_t s) {
     const int OH = (IH + 2 * L.pad - L.kh) / L.stride + 1, OW = (IW + 2 * L.pad - L.kw) / L.stride + 1;
@@ -142,12 +146,13 @@ int conv_layer(int dtype, const mic_conv_layer& L, const void* in, int B, int IH
     d.in_img_stride = (int64_t)IH * IW * L.cin; d.in_row_stride = (int64_t)IW * L.cin; d.in_pix_stride = L.cin;
     d.kw_taps = L.kw; d.run = L.cin; d.stride = L.stride; d.pad_h = d.pad_w = L.pad;
     d.ldc = L.cout; d.ld_res = L.cout; d.relu = L.relu;
+    d.scratch = t_conv_scratch; d.scratch_bytes = t_conv_scratch_bytes;
     *OHo = OH; *OWo = OW;
     return mic_conv2d(&d, s);
 }
 
 struct ResnetPlan {
-    int64_t pack, big, mid, total;
+    int64_t pack, big, mid, scratch, total;
     int Hp, Wp, H1, W1, H2, W2;
 };
 
@@ -162,7 +167,8 @@ ResnetPlan plan_resnet(const mic_resnet50* net, int B, int H, int W) {
     const int64_t l1 = (int64_t)B * p.H2 * p.W2 * 256;
     p.big = align_up((stem > l1 ? stem : l1) * sz, 256);
     p.mid = align_up((int64_t)B * p.H2 * p.W2 * 128 * sz, 256);
-    p.total = p.pack + 3 * p.big + 2 * p.mid;
+    p.scratch = net->dtype == MIC_BF16 ? mic_conv2d_scratch_bytes() : 0;
+    p.total = p.pack + 3 * p.big + 2 * p.mid + p.scratch;
     return p;
 }
 
@@ -198,6 +204,12 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
     void* DS = base + p.pack + 2 * p.big;
     void* T1 = base + p.pack + 3 * p.big;             // first-convolution output of the running block
     void* T2 = base + p.pack + 3 * p.big + p.mid;     // 3x3 output, or the next block's first-convolution output
+    // split-K scratch of the late layers: its tickets start every forward pass at zero
+    struct ScratchScope {
+        ScratchScope(void* p, int64_t n) { t_conv_scratch = p; t_conv_scratch_bytes = n; }
+        ~ScratchScope() { t_conv_scratch = nullptr; t_conv_scratch_bytes = 0; }
+    } scratch_scope(p.scratch ? base + p.pack + 3 * p.big + 2 * p.mid : nullptr, p.scratch);
+    if (p.scratch) MIC_HIP_CHECK(hipMemsetAsync(t_conv_scratch, 0, 4096, s));
 
     // stem: image -> zero-bordered 4-channel pixels; each of the 7 kernel rows is one run of
     // 8 pixels x 4 channels = 32 contiguous elements (the 8th pixel and 4th channel meet zero weights)
@@ -314,6 +326,7 @@ extern "C" int mic_resnet50_forward(const mic_resnet50* net, const float* images
                 d.in_img_stride = (int64_t)h2 * w2 * F.cin_main; d.in_row_stride = (int64_t)w2 * F.cin_main; d.in_pix_stride = F.cin_main;
                 d.kw_taps = 1; d.run = F.cin_main; d.stride = 1;
                 d.ldc = F.cout; d.relu = 1;
+                d.scratch = t_conv_scratch; d.scratch_bytes = t_conv_scratch_bytes;
                 d.in2 = X[cur]; d.K2 = F.cin_skip; d.stride2 = F.skip_stride;
                 d.in2_img_stride = (int64_t)h * w * F.cin_skip; d.in2_row_stride = (int64_t)w * F.cin_skip; d.in2_pix_stride = F.cin_skip;
                 MIC_TRY(mic_conv2d(&d, s));

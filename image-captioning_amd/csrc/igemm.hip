@@ -543,10 +543,19 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
             v = t64 > 256 ? 4 : 5;
         }
     }
+    // bf16, long K: the eight-phase 256 x 256 variant where it has a tile for most compute units, or can split K to get there
+    // (measured on the ResNet-50 layers at batch 256: stage 2 and 3 layers with K >= 1024)
+    bool eight = false;
+    if constexpr (sizeof(T) == 2) {
+        if (forced < 0 && a.Kt >= 1024 && mic_igemm8_supported(a)) {
+            const long long t256 = (long long)((a.M + 255) / 256) * (a.N / 256);
+            eight = t256 >= 150 || mic_igemm8_splitk(a) * t256 >= 150;
+        }
+    }
     if (a.in2) {
         // two-segment K (fused bottleneck tails): measured on the four ResNet-50 shapes at batch 256
         const int epr = 64 / (int)sizeof(T);
-        if (forced < 0) v = a.N % 256 != 0 ? 0 : (a.Kt < 256 || a.K % (2 * epr) != 0) ? 11 : 16;
+        if (forced < 0) v = eight ? 18 : a.N % 256 != 0 ? 0 : (a.Kt < 256 || a.K % (2 * epr) != 0) ? 11 : 16;
         switch (v) {
             case 11: return launch<T, 128, 256, 1, 2, 4, false, false, 2, true>(a, s, flops);
             case 16: return launch<T, 256, 256, 2, 4, 4, false, true, 2, true>(a, s, flops);
@@ -554,6 +563,7 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
             default: return launch<T, 128, 128, 1, 2, 2, false, false, 2, true>(a, s, flops);
         }
     }
+    if (eight) v = 18;
     static const int res_pre = [] {
         const char* e = getenv("MIC_IGEMM_RES_PRE");
         return e ? atoi(e) : 1;
@@ -666,6 +676,7 @@ int conv2d_impl(const mic_conv_desc* d, void* stream, int variant) {
     IgemmArgs a;
     a.in = d->in; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
     a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.ln_yt = d->ln_out; a.ld_yt = d->ld_ln_out;
+    a.scratch = d->scratch; a.scratch_bytes = d->scratch ? d->scratch_bytes : 0; a.splitk = 1;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.in2 = d->in2; a.K2 = d->in2 ? d->K2 : 0; a.Kt = a.K + a.K2;
     a.img_stride2 = d->in2_img_stride; a.row_stride2 = d->in2_row_stride; a.pix_stride2 = d->in2_pix_stride; a.stride2 = d->stride2;

@@ -26,6 +26,10 @@ struct IgemmArgs {
     const float* ln_b;
     void* ln_yt;
     int ld_yt;
+    // split-K scratch of the 256 x 256 eight-phase variant: tickets (zero between launches) then fp32 partial tiles
+    void* scratch;
+    long long scratch_bytes;
+    int splitk;
 };
 
 namespace {
@@ -176,4 +180,5 @@ template <bool RES_PRE> __device__ __forceinline__ void igemm_finish_chunk(const
 
 // the eight-phase 256 x 256 bf16 variant (igemm8.hip): whether it takes the problem, and its launch
 bool mic_igemm8_supported(const IgemmArgs& a);
+int mic_igemm8_splitk(const IgemmArgs& a);  // slices per tile the launch would use (1: no split)
 int mic_igemm8_launch(IgemmArgs& a, hipStream_t s, double flops);

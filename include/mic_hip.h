@@ -96,11 +96,20 @@ typedef struct mic_conv_desc {
     const float* ln_beta;
     void* ln_out;
     int32_t ld_ln_out;
+    /* Optional scratch (NULL = none) that lets a layer with fewer 256 x 256 output tiles than the GPU has compute units
+     * split K over several workgroups per tile (bf16, tile variant 18): 4 KiB of tickets, which must be zero before the
+     * first launch and are left zero by every launch, then one fp32 partial tile of 256 KiB per (tile, slice);
+     * mic_conv2d_scratch_bytes() is the size that serves every layer (a split never has more than 256 slices).  Launches that
+     * share a scratch must be ordered on one stream.  Results of a split layer agree with the unsplit one to fp32 rounding of
+     * the regrouped sum (the bf16 outputs can differ in the last bit).  No reference counterpart. */
+    void* scratch;
+    int64_t scratch_bytes;
 } mic_conv_desc;
 int mic_conv2d(const mic_conv_desc* d, void* stream);
 int mic_conv2d_ln_supported(int N);
+int64_t mic_conv2d_scratch_bytes(void);
 /* The same layer on a named tile variant instead of the one the shape heuristic picks (0: 128x128, 1: 128x128 with
- * 128-byte stages, 4: 64x64, 8: 128x64, 11: 128x256, 16: 256x256 filled directly into LDS, ...; the list is in
+ * 128-byte stages, 4: 64x64, 8: 128x64, 11: 128x256, 16: 256x256 filled directly into LDS, 18: 256x256 in eight phases (bf16), ...; the list is in
  * csrc/igemm.hip).  Every variant computes the same result for every shape; this entry exists for tuning sweeps and
  * for per-variant parity tests.  No reference counterpart. */
 int mic_conv2d_variant(const mic_conv_desc* d, int variant, void* stream);

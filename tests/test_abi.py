@@ -77,7 +77,8 @@ def test_argument_errors_need_no_gpu():
     net = L.Resnet50()
     net.dtype = L.BF16
     b256 = L.lib.mic_resnet50_workspace_bytes(C.byref(net), 256, 224, 224)
-    assert 1_700_000_000 < b256 < 1_800_000_000  # packed image + 3 x (256*112*112*64) + 2 x (256*56*56*128) bf16
+    # packed image + 3 x (256*112*112*64) + 2 x (256*56*56*128) bf16 + the split-K scratch of the late layers
+    assert 1_700_000_000 < b256 - L.lib.mic_conv2d_scratch_bytes() < 1_800_000_000
     sw = L.Swin()
     sw.dtype, sw.embed_dim = L.BF16, 96
     for i, (dp, hd) in enumerate(zip((2, 2, 18, 2), (3, 6, 12, 24))):

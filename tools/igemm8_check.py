@@ -17,7 +17,17 @@ L, W = amd._lib, amd.weights
 DEV = "cuda:0"
 
 
-def conv(variant, x, wm, bias, res, B, Ci, H, Wd, Co, k, stride, pad, relu=1):
+_SCRATCH = {}
+
+
+def scratch():
+    """One zeroed split-K scratch per process (the launches leave its tickets zero)."""
+    if "t" not in _SCRATCH:
+        _SCRATCH["t"] = torch.zeros(int(L.lib.mic_conv2d_scratch_bytes()), dtype=torch.uint8, device=DEV)
+    return _SCRATCH["t"]
+
+
+def conv(variant, x, wm, bias, res, B, Ci, H, Wd, Co, k, stride, pad, relu=1, split=True):
     OH, OW = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
     out = torch.empty(B, OH, OW, Co, dtype=torch.bfloat16, device=DEV)
     d = L.ConvDesc()
@@ -28,6 +38,8 @@ def conv(variant, x, wm, bias, res, B, Ci, H, Wd, Co, k, stride, pad, relu=1):
     d.in_img_stride, d.in_row_stride, d.in_pix_stride = H * Wd * Ci, Wd * Ci, Ci
     d.kw_taps, d.run, d.stride, d.pad_h, d.pad_w = k, Ci, stride, pad, pad
     d.ldc, d.ld_res, d.relu, d.w_rows = Co, Co, relu, wm.shape[0]
+    if split:
+        d.scratch, d.scratch_bytes = scratch().data_ptr(), scratch().numel()
     if variant < 0:
         L.check(L.lib.mic_conv2d(C.byref(d), L.stream_ptr()), "mic_conv2d")
     else:
@@ -40,7 +52,9 @@ CASES = [  # B, Ci, H, W, Co, k, stride, pad, residual
     (2, 64, 14, 14, 512, 3, 1, 1, False),    # 9 K-tiles (odd), taps outside the image
     (2, 128, 15, 15, 256, 3, 2, 1, False),   # stride 2, 18 K-tiles
     (1, 192, 9, 9, 256, 1, 1, 0, True),      # 3 K-tiles, M = 81
-    (5, 256, 14, 14, 768, 3, 1, 1, True),    # several tiles in both directions, 36 K-tiles
+    (5, 256, 14, 14, 768, 3, 1, 1, True),    # several tiles in both directions, 36 K-tiles (with a scratch: one slice; four of 9 under MIC_IGEMM8_SPLITK=4)
+    (3, 512, 7, 7, 256, 3, 1, 1, False),     # one tile, 72 K-tiles: three slices of 24
+    (2, 320, 9, 9, 512, 1, 1, 0, True),      # 5 K-tiles: too short to split
 ]
 
 
@@ -62,15 +76,22 @@ def check():
         wm = W.conv_matrix(w, torch.bfloat16, DEV)
         rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
         bd = b.to(DEV)
-        o18, _ = conv(18, xd, wm, bd, rd, B, Ci, H, Wd, Co, k, s, p)  # honours MIC_IGEMM8_* like every launch of variant 18
+        o18, _ = conv(18, xd, wm, bd, rd, B, Ci, H, Wd, Co, k, s, p, split=False)
+        o18s, _ = conv(18, xd, wm, bd, rd, B, Ci, H, Wd, Co, k, s, p, split=True)
+        o18s2, _ = conv(18, xd, wm, bd, rd, B, Ci, H, Wd, Co, k, s, p, split=True)
         o0, _ = conv(0, xd, wm, bd, rd, B, Ci, H, Wd, Co, k, s, p)
         torch.cuda.synchronize()
         got = o18.float().cpu().permute(0, 3, 1, 2)
         err = (got - ref).abs().max().item()
         same = torch.equal(o18, o0)
         close = torch.allclose(got, ref, rtol=2e-2, atol=2e-2)
-        print(f"case {case}: max |err| vs fp32 {err:.4f}  close={close}  bit-equal to variant 0: {same}", flush=True)
-        ok = ok and close and same
+        # with a scratch the layer may split K: regrouped fp32 sum, the bf16 result within one rounding step of the unsplit one
+        d_split = (o18s.float() - o18.float()).abs().max().item()
+        split_ok = torch.allclose(o18s.float(), o18.float(), rtol=8e-3, atol=1e-3) and torch.equal(o18s, o18s2)
+        tickets_zero = int(scratch()[:4096].to(torch.int32).sum().item()) == 0
+        print(f"case {case}: max |err| vs fp32 {err:.4f}  close={close}  bit-equal to variant 0: {same}  "
+              f"with scratch: max |diff| {d_split:.4f} ok={split_ok} tickets zero={tickets_zero}", flush=True)
+        ok = ok and close and same and split_ok and tickets_zero
     return ok
 
 
