@@ -102,7 +102,7 @@ VARIANT_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_conv2d_every_tile_variant(amd, variant, dtype):
     L, W = amd._lib, amd.weights
     tol = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
@@ -126,6 +126,80 @@ def test_conv2d_every_tile_variant(amd, variant, dtype):
         np.testing.assert_allclose(got.numpy(), ref.numpy(), err_msg=f"variant {variant} case {case}", **tol)
 
 
+EIGHT_PHASE_CASES = [
+    # B, Ci, H, W, Co, k, stride, pad, residual: N a multiple of 256 and channels a multiple of 64, as variant 18 requires
+    (3, 64, 13, 11, 256, 1, 1, 0, True),     # one K-tile, M = 429: a partial second row tile
+    (2, 64, 14, 14, 512, 3, 1, 1, False),    # 9 K-tiles (odd count), taps outside the image
+    (2, 128, 15, 15, 256, 3, 2, 1, False),   # stride 2, 18 K-tiles
+    (1, 192, 9, 9, 256, 1, 1, 0, True),      # 3 K-tiles, M = 81
+    (5, 256, 14, 14, 768, 3, 1, 1, True),    # several tiles in both directions, 36 K-tiles
+    (3, 512, 7, 7, 256, 3, 1, 1, False),     # one tile, 72 K-tiles: split three ways when a scratch is given
+]
+
+
+@pytest.mark.parametrize("splitk", ["none", "auto", "4"])
+def test_conv2d_eight_phase_variant(amd, splitk, monkeypatch):
+    """Tile variant 18 (256x256, eight phases, bf16): against torch's fp32 convolution, bit for bit against variant 0 when K
+    is not split, within one bf16 rounding step of it when it is (the fp32 sum is regrouped); the tickets of the scratch are
+    zero again after every launch, and two launches give the same bits."""
+    L, W = amd._lib, amd.weights
+    if splitk == "4":
+        monkeypatch.setenv("MIC_IGEMM8_SPLITK", "4")
+    scratch = torch.zeros(int(L.lib.mic_conv2d_scratch_bytes()), dtype=torch.uint8, device=DEV) if splitk != "none" else None
+    for case in EIGHT_PHASE_CASES:
+        B, Ci, H, Wd, Co, k, s, p, use_res = case
+        g = torch.Generator().manual_seed(sum(case))
+        x = torch.randn(B, Ci, H, Wd, generator=g).bfloat16().float()
+        w = (torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)).bfloat16().float()
+        b = torch.randn(Co, generator=g)
+        ref = F.conv2d(x, w, b, s, p)
+        res = None
+        if use_res:
+            res = torch.randn(ref.shape, generator=g).bfloat16().float()
+            ref = ref + res
+        ref = F.relu(ref)
+        outs = []
+        for variant, scr in ((0, None), (18, scratch), (18, scratch)):
+            OH, OW = (H + 2 * p - k) // s + 1, (Wd + 2 * p - k) // s + 1
+            xd = x.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
+            wm = W.conv_matrix(w, torch.bfloat16, DEV)
+            out = torch.empty(B, OH, OW, Co, dtype=torch.bfloat16, device=DEV)
+            rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
+            bd = b.to(DEV)
+            d = L.ConvDesc()
+            d.in_, d.w, d.bias, d.res, d.out = xd.data_ptr(), wm.data_ptr(), bd.data_ptr(), L.ptr(rd), out.data_ptr()
+            d.dtype = d.out_dtype = d.res_dtype = L.BF16
+            d.M, d.N, d.K = B * OH * OW, Co, k * k * Ci
+            d.OH, d.OW, d.IH, d.IW = OH, OW, H, Wd
+            d.in_img_stride, d.in_row_stride, d.in_pix_stride = H * Wd * Ci, Wd * Ci, Ci
+            d.kw_taps, d.run, d.stride, d.pad_h, d.pad_w = k, Ci, s, p, p
+            d.ldc, d.ld_res, d.relu, d.w_rows = Co, Co, 1, wm.shape[0]
+            if scr is not None:
+                d.scratch, d.scratch_bytes = scr.data_ptr(), scr.numel()
+            L.check(L.lib.mic_conv2d_variant(C.byref(d), variant, L.stream_ptr()), f"mic_conv2d_variant({variant})")
+            torch.cuda.synchronize()
+            outs.append(out)
+        v0, a18, b18 = outs
+        np.testing.assert_allclose(a18.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=2e-2, atol=2e-2, err_msg=f"case {case}")
+        assert torch.equal(a18, b18), f"two launches differ, case {case}"
+        if splitk == "none":
+            assert torch.equal(a18, v0), f"variant 18 differs from variant 0, case {case}"
+        else:
+            np.testing.assert_allclose(a18.float().cpu().numpy(), v0.float().cpu().numpy(), rtol=8e-3, atol=1e-3, err_msg=f"case {case}")
+            assert int(scratch[:4096].to(torch.int32).sum().item()) == 0, "tickets left behind"
+    # shapes the variant does not take are refused, not mis-computed
+    x = torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16)
+    wm = torch.zeros(128, 64, device=DEV, dtype=torch.bfloat16)
+    out = torch.zeros(64, 128, device=DEV, dtype=torch.bfloat16)
+    d = L.ConvDesc()
+    d.in_, d.w, d.out = x.data_ptr(), wm.data_ptr(), out.data_ptr()
+    d.dtype = d.out_dtype = d.res_dtype = L.BF16
+    d.M, d.N, d.K, d.OH, d.OW, d.IH, d.IW = 64, 128, 64, 1, 1, 1, 1
+    d.in_img_stride, d.in_pix_stride, d.kw_taps, d.run, d.stride, d.ldc, d.w_rows = 64, 64, 1, 64, 1, 128, 128
+    assert L.lib.mic_conv2d_variant(C.byref(d), 18, L.stream_ptr()) == -1 and b"eight-phase" in L.lib.mic_last_error()
+    torch.cuda.synchronize()
+
+
 def test_conv2d_rejects_a_weight_matrix_that_is_not_padded(amd):
     """Tiles fetch whole 128-row groups of the weight matrix: a matrix stated to be shorter is refused."""
     L = amd._lib
@@ -141,7 +215,7 @@ def test_conv2d_rejects_a_weight_matrix_that_is_not_padded(amd):
     for v in (-1, 0, 16):
         rc = L.lib.mic_conv2d(C.byref(d), L.stream_ptr()) if v < 0 else L.lib.mic_conv2d_variant(C.byref(d), v, L.stream_ptr())
         assert rc == -1 and b"zero-padded to 128" in L.lib.mic_last_error()
-    assert L.lib.mic_conv2d_variant(C.byref(d), 18, L.stream_ptr()) == -1
+    assert L.lib.mic_conv2d_variant(C.byref(d), 19, L.stream_ptr()) == -1
     torch.cuda.synchronize()
 
 
