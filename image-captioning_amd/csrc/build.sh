@@ -10,7 +10,7 @@ PIDS=""
 mkdir -p build
 for f in mic_core igemm igemm8 fused_block stem_pool gemm_ln pool decode_ops attn_fused decode_persist search_ops swin drivers noalloc; do
   [ -f $f.hip ] || continue
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ mic_common.h -nt build/$f.o ] || [ decode_shared.h -nt build/$f.o ] || [ igemm_shared.h -nt build/$f.o ] || [ ../../include/mic_hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ mic_common.h -nt build/$f.o ] || [ decode_shared.h -nt build/$f.o ] || [ igemm_shared.h -nt build/$f.o ] || [ search_shared.h -nt build/$f.o ] || [ ../../include/mic_hip.h -nt build/$f.o ]; then
     # compile to a temporary name: an interrupted or failed compile leaves no object behind
     ( $HIPCC $FLAGS -c $f.hip -o build/$f.o.tmp && mv build/$f.o.tmp build/$f.o ) &
     PIDS="$PIDS $!"

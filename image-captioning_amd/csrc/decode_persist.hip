@@ -29,6 +29,7 @@
 // the step is held to bit-equality with mic_tr_step by tests/test_gpu_persist.py.
 #include "mic_common.h"
 #include "decode_shared.h"
+#include "search_shared.h"
 
 #include <atomic>
 
@@ -127,6 +128,8 @@ struct PersistArgs {
     unsigned* sync;   // [clusters][MAX_SEAMS] seam counters, then the error word
     int N, B, R, S, t, t_cap, L, V, attn_mode, clusters;
     int stop_seam;  // diagnostic: the launch ends once this seam has been arrived at (-1: never)
+    TailArgs tail;    // the beam-search tail of the step as a last phase (has_tail)
+    int has_tail;
     unsigned long long* trace;  // diagnostic: [workgroup][128] 100 MHz time stamps, or null
 };
 
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
     const int xl = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cluster = (slot / CL) * 8 + xl, j = slot % CL;
     if (cluster >= a.clusters) return;
-    const int nseams = 4 * a.L;
+    const int nseams = 4 * a.L + (a.has_tail ? 1 : 0);
 
     Seam seam;
     seam.cnt = a.sync + (size_t)cluster * MAX_SEAMS;
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
             if (seam_idx - 1 == a.stop_seam) return;
         }
     }
-    {   // ---- E: vocabulary projection (read by the next launch: plain stores) ----
+    {   // ---- E: vocabulary projection ----
         int wave, lane;
         who(wave, lane);
         GemmIO<T> io{};
@@ -997,8 +1000,29 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
         io.wf = a.out_wf; io.bias = a.out_b;
         io.out = r_logits; io.ldc_b = (unsigned)a.V * 4u; io.out_plain = a.logits; io.out_f32 = true; io.N = a.V;
         io.CB = (a.V + 127) / 128; io.shift = 0;
-        if (!gemm_phase<T, RG, 16, PARTS, false>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane, a.trace)) return;
+        if (!gemm_phase<T, RG, 16, PARTS, true>(io, seam, seam_idx - 1, j, m0, N, work, rs_x, rs_r, red, wave, lane, a.trace)) return;
         stamp(a.trace, 3 * seam_idx + 2);
+    }
+    if constexpr (RG >= 2) {
+        if (a.has_tail) {   // ---- F: log-softmax + top-K of the image's rows, beam selection, the next position's embedding ----
+            seam_arrive(seam, seam_idx++);
+            stamp(a.trace, 3 * seam_idx);
+            int wave, lane;
+            who(wave, lane);
+            if (has_image) {
+                int t = threadIdx.x;
+                asm volatile("" : "+v"(t));
+                constexpr int GW = RG <= 2 ? 256 : 128;  // as the stand-alone tail launch: the same sums in the same order
+                auto& ts = *reinterpret_cast<TailShared<RG, NT / GW, GW / 64>*>(work);
+                beam_tail_body<RG, GW, NT / GW, true>(a.tail, b, t, ts, [&] {
+                    seam_poll(seam, seam_idx - 1, wave);
+                    const bool ok = seam_join(seam);
+                    stamp(a.trace, 120);
+                    return ok;
+                });
+            }
+            stamp(a.trace, 121);
+        }
     }
 }
 
@@ -1063,10 +1087,25 @@ bool mic_tr_persist_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* 
            dec->vocab % 4 == 0 && (long long)ws->N * dec->vocab * 4 < (1ll << 31);
 }
 
+// Whether the beam-search tail of a step (K beams over V words) can run as the last phase of the one-launch step: two
+// (K = 2) or four (K = 3) groups of threads hold a row of up to 4096 logits each, one seam more.
+bool mic_tr_persist_tail_ok(const mic_tr_decoder* dec, const mic_tr_workspace* ws, int K, int V) {
+    static const bool off = getenv("MIC_NO_PERSIST_TAIL") != nullptr;
+    return !off && K >= 2 && K == ws->rows_per_image && K <= 3 && V == dec->vocab && V <= 4096 && 4 * dec->layers + 1 <= MAX_SEAMS && dec->H % 4 == 0;
+}
+
 // The layers and the vocabulary projection of one step on the residual stream already in ws->x / ws->xt (the embedding
 // is the caller's: mic_embed_pos, or the beam tail of the previous step).
-int mic_tr_persist_launch(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* anc, int t, int attn_mode, hipStream_t s) {
+int mic_tr_persist_launch(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* anc, int t, int attn_mode,
+                          const mic_beam_tail_desc* tail, hipStream_t s) {
     PersistArgs a{};
+    if (tail) {
+        MIC_ARG_CHECK(mic_tr_persist_tail_ok(dec, ws, tail->K, tail->V) && tail->B * tail->K == ws->N && tail->logits == ws->logits &&
+                          tail->ld == dec->vocab && tail->n_gather == 0,
+                      "mic_tr_step: the beam tail does not fit the one-launch step");
+        MIC_TRY(tail_args_from_desc(tail, a.tail));
+        a.has_tail = 1;
+    }
     for (int l = 0; l < dec->layers; ++l) {
         const mic_tr_layer& Y = dec->layer[l];
         PLayer& p = a.layer[l];

@@ -629,7 +629,8 @@ bool mic_tr_fused_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* ws
 }
 
 int mic_tr_step_impl(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
-                     int attn_mode, bool skip_embed, void* stream, bool allow_persist = false);
+                     int attn_mode, bool skip_embed, void* stream, bool allow_persist = false, const mic_beam_tail_desc* tail = nullptr,
+                     bool* tail_done = nullptr);
 
 extern "C" int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok,
                            const int32_t* anc, int t, int attn_mode, void* stream) {
@@ -653,7 +654,7 @@ extern "C" int mic_tr_step_schedule(const mic_tr_decoder* dec, const mic_tr_work
 }
 
 int mic_tr_step_impl(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* tokens, int ld_tok, const int32_t* anc, int t,
-                     int attn_mode, bool skip_embed, void* stream, bool allow_persist) {
+                     int attn_mode, bool skip_embed, void* stream, bool allow_persist, const mic_beam_tail_desc* tail, bool* tail_done) {
     MIC_TRY(check_tr(dec, ws));
     MIC_ARG_CHECK(tokens && t >= 0 && t < ws->t_cap && t < dec->pos_rows, "mic_tr_step: position %d outside t_cap=%d / table=%d", t,
                   ws->t_cap, dec->pos_rows);
@@ -662,7 +663,10 @@ int mic_tr_step_impl(const mic_tr_decoder* dec, const mic_tr_workspace* ws, cons
     const int dt = dec->dtype, H = dec->H, N = ws->N, S = ws->S, L = dec->layers;
     if (allow_persist && mic_tr_persist_eligible(dec, ws)) {
         if (!skip_embed) MIC_TRY(mic_embed_pos(tokens, ld_tok, t, dec->tok_emb, dec->pos_emb, ws->x, ws->xt, H, dt, N, H, dec->vocab, s));
-        return mic_tr_persist_launch(dec, ws, anc, t, attn_mode, s);
+        // the beam-search tail rides along as the launch's last phase where it fits
+        const bool with_tail = tail && mic_tr_persist_tail_ok(dec, ws, tail->K, tail->V);
+        if (tail_done) *tail_done = with_tail;
+        return mic_tr_persist_launch(dec, ws, anc, t, attn_mode, with_tail ? tail : nullptr, s);
     }
     if (ws->qkvf && mic_tr_fused_eligible(dec, ws)) return tr_step_fused(dec, ws, tokens, ld_tok, anc, t, attn_mode, skip_embed, s);
     MIC_ARG_CHECK(ws->qkv && ws->o, "mic_tr_step: this shape does not take the fused-attention step and needs the qkv and o buffers");
@@ -710,13 +714,19 @@ extern "C" int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspa
         for (int t = t0; t < t1; ++t) {
             const mic_beam_state* cur = &st[t & 1];
             const mic_beam_state* nxt = &st[(t + 1) & 1];
-            MIC_TRY(mic_tr_step_impl(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, tail && t > t0, stream, true));
             if (tail) {
-                MIC_TRY(mic_beam_tail(ws->logits, dec->vocab, dec->vocab, cur, nxt, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t,
-                                      ws->t_cap, eos_id, t + 1 < t1 ? dec->tok_emb : nullptr, dec->pos_emb, ws->x, ws->xt, dec->dtype, dec->H,
-                                      dec->vocab, stream));
+                mic_beam_tail_desc d{};
+                d.logits = ws->logits; d.ld = dec->vocab; d.V = dec->vocab; d.cur = cur; d.nxt = nxt; d.parent = parent;
+                d.live_images = live_images + t; d.sqrt_tab = sqrt_tab;
+                d.B = B; d.K = K; d.n_live_slots = t == 0 ? 1 : K; d.t = t; d.t_cap = ws->t_cap; d.eos_id = eos_id;
+                d.tok_emb = t + 1 < t1 ? dec->tok_emb : nullptr; d.pos_emb = dec->pos_emb; d.x = ws->x; d.xt = ws->xt; d.ld_xt = dec->H;
+                d.dtype = dec->dtype; d.H = dec->H; d.vocab = dec->vocab;
+                bool done = false;
+                MIC_TRY(mic_tr_step_impl(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, t > t0, stream, true, &d, &done));
+                if (!done) MIC_TRY(mic_beam_tail_ex(&d, stream));
                 continue;
             }
+            MIC_TRY(mic_tr_step_impl(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, false, stream, true));
             MIC_TRY(mic_logsoftmax_topk(ws->logits, dec->vocab, ws->N, dec->vocab, K, 1.0f, 0, ws->top_val, ws->top_idx, nullptr, stream));
             MIC_TRY(mic_beam_select(cur, nxt, ws->top_val, ws->top_idx, parent, live_images + t, sqrt_tab, B, K, t == 0 ? 1 : K, t,
                                     ws->t_cap, eos_id, 0, stream));

@@ -81,7 +81,10 @@ bool mic_tr_fused_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* ws
 // the one-launch step (decode_persist.hip): whether (dec, ws) can take it, and the launch of the layers and the vocabulary
 // projection on the residual stream already in ws->x / ws->xt
 bool mic_tr_persist_eligible(const mic_tr_decoder* dec, const mic_tr_workspace* ws);
-int mic_tr_persist_launch(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* anc, int t, int attn_mode, hipStream_t s);
+// `tail` (or null): the beam-search tail of the step, run as the launch's last phase (mic_tr_persist_tail_ok)
+bool mic_tr_persist_tail_ok(const mic_tr_decoder* dec, const mic_tr_workspace* ws, int K, int V);
+int mic_tr_persist_launch(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int32_t* anc, int t, int attn_mode,
+                          const mic_beam_tail_desc* tail, hipStream_t s);
 
 // ---- element types ----
 typedef __bf16 bf16_t;

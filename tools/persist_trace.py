@@ -43,7 +43,11 @@ def main():
         work = (done - ready)[act]
         allarr = arr[arr > 0] - t0 if p < len(names) - 1 else torch.tensor([0.0])
         print(f"{name:14s} {int(act.sum()):6d} {r.mean():9.2f}/{r.max():8.2f} {work.mean():10.2f} {work.max():9.2f} {d.max():9.2f} {allarr.max():10.2f}")
-    print(f"kernel span: {(tr[:, 1:40].max() - t0):.2f} us")
+    if (tr[:, 121] > 0).any():
+        act = tr[:, 120] > 0
+        print(f"{'beam tail':14s} {int(act.sum()):6d} {(tr[act, 120] - t0).mean():9.2f}/{(tr[act, 120] - t0).max():8.2f} "
+              f"{(tr[act, 121] - tr[act, 120]).mean():10.2f} {(tr[act, 121] - tr[act, 120]).max():9.2f} {(tr[act, 121] - t0).max():9.2f}")
+    print(f"kernel span: {(tr[:, 1:].max() - t0):.2f} us")
     print("inside the GEMM phases, microseconds after 'ready' (mean over active workgroups): stats merged, rows loaded, rows staged, products done, epilogue values, statistics, outputs stored")
     for p, name in enumerate(names):
         if "attention" in name:
