@@ -35,8 +35,12 @@ namespace {
 // LN: the tile spans whole output rows (one n-tile) and the epilogue is LayerNorm over the row followed by the optional
 // residual add; the fp32 tile is staged 32 rows at a time and every wave then owns whole rows, one float4 per lane per 256
 // columns, the summation order of the stand-alone layernorm_kernel (so fusing changes no bit of the result).
+// BUFX (register staging only): operands are loaded through buffer descriptors at 32-bit byte offsets; a tap outside the
+// image, a row outside the problem and a k past the end of K are bit 31 of the offset, for which the hardware returns zeros.
+// One add and two bit operations per load replace two 64-bit multiply-adds, four compares and a branch around the load.
+// Needs tensors of less than 2 GiB and at most 31 taps (igemm_fits_buffers).
 template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false,
-          bool LN = false>
+          bool LN = false, bool BUFX = false>
 __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(const IgemmArgs a) {
     constexpr int NW = WM * WN, NT = 64 * NW;  // waves, threads
     constexpr int RW = BM / WM, CW = BN / WN;  // rows / columns per wave
@@ -110,7 +114,62 @@ __global__ __launch_bounds__(64 * WM * WN, RES_PRE ? 3 : 1) void igemm_kernel(co
         kw = tap - kh * a.kw_taps;
     }
     uint4 xr[XC], wr[WC];
+    // buffer form of the same addresses
+    unsigned bx_off[BUFX ? XC : 1], bx2_off[BUFX && SEG2 ? XC : 1], bx_bad[BUFX ? XC : 1], bw_off[BUFX ? WC : 1];
+    unsigned tap = 0, tapb = 0;  // tap index of k_cur and the byte offset of that tap from tap (0, 0)
+    const unsigned rowb = (unsigned)a.row_stride * (unsigned)sizeof(T), pixb = (unsigned)a.pix_stride * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), (short)0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), (short)0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(SEG2 ? a.in2 : a.in), (short)0, (int)0x80000000u, 0x00020000);
+    if constexpr (BUFX) {
+        const int kh_taps = a.K / a.run / a.kw_taps;
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+            bx_off[i] = (unsigned)((x_img[i] + (long long)x_h[i] * a.row_stride + (long long)x_w[i] * a.pix_stride) * (long long)sizeof(T));
+            if constexpr (SEG2) bx2_off[i] = (unsigned)((const char*)x2_p[i] - (const char*)a.in2);
+            unsigned bad = x_ok[i] ? 0u : 0xffffffffu;
+            for (int th = 0, tp = 0; th < kh_taps; ++th)
+                for (int tw = 0; tw < a.kw_taps; ++tw, ++tp)
+                    if (!((unsigned)(x_h[i] + th) < (unsigned)a.IH && (unsigned)(x_w[i] + tw) < (unsigned)a.IW)) bad |= 1u << tp;
+            bx_bad[i] = bad;
+        }
+#pragma unroll
+        for (int i = 0; i < WC; ++i)
+            bw_off[i] = (unsigned)(((long long)(n0 + row0 + i * RSTEP) * a.Kt + kt_own * EPR + q_own * VEC) * (long long)sizeof(T)) | (w_ok[i] ? 0u : 0x80000000u);
+        tap = (unsigned)(kh * a.kw_taps + kw);
+        tapb = (unsigned)kh * rowb + (unsigned)kw * pixb;
+    }
     auto load_stage = [&]() {
+        if constexpr (BUFX) {
+            const unsigned dead = k_cur < a.Kt ? 0u : 0x80000000u;
+            const bool seg1 = !SEG2 || k_cur < a.K;
+            const unsigned sb = seg1 ? tapb + (unsigned)c0 * (unsigned)sizeof(T) : (unsigned)(k_cur - a.K) * (unsigned)sizeof(T);
+            const unsigned bit = seg1 ? tap : 31u;
+#pragma unroll
+            for (int i = 0; i < XC; ++i) {
+                unsigned base = bx_off[i];
+                if constexpr (SEG2) base = seg1 ? base : bx2_off[i];
+                // an offset that wrapped below zero (a tap above or left of the first image) has bit 31 set as well
+                const unsigned off = (base + sb) | (__builtin_amdgcn_ubfe(bx_bad[i], bit, 1) << 31) | dead;
+                const auto v = SEG2 ? __builtin_amdgcn_raw_buffer_load_b128(seg1 ? rs_x : rs_x2, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+                xr[i] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < WC; ++i) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bw_off[i] | dead, 0, 0);
+                wr[i] = make_uint4(v[0], v[1], v[2], v[3]);
+                bw_off[i] += KT * EPR * (unsigned)sizeof(T);
+            }
+            k_cur += KT * EPR;
+            c0 += KT * EPR;
+            while (c0 >= a.run) {
+                c0 -= a.run;
+                ++tap;
+                tapb += pixb;
+                if (++kw == a.kw_taps) { kw = 0; ++kh; tapb += rowb - (unsigned)a.kw_taps * pixb; }
+            }
+            return;
+        }
         const bool k_ok = k_cur < a.Kt;
         if (!SEG2 || k_cur < a.K) {
 #pragma unroll
@@ -492,7 +551,7 @@ void* mic_prof_open_scope(hipStream_t s, int slot) {
 namespace {
 
 template <typename T, int BM, int BN, int KT, int WM = 2, int WN = 2, bool RES_PRE = false, bool GLDS = false, int NS = 2, bool SEG2 = false,
-          bool LN = false>
+          bool LN = false, bool BUFX = false>
 int launch(IgemmArgs& a, hipStream_t s, double flops) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
@@ -500,7 +559,7 @@ int launch(IgemmArgs& a, hipStream_t s, double flops) {
     constexpr int kstage = KT * 64 / (int)sizeof(T);
     a.nk = (a.Kt + kstage - 1) / kstage;
     void* rec = mic_prof_open(s, (BM >= 128 ? 0 : 2) + (sizeof(T) == 2 ? 1 : 0), flops);  // tiles of 128 rows and more share a slot
-    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT, WM, WN, RES_PRE, GLDS, NS, SEG2, LN>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
+    MIC_LAUNCH((igemm_kernel<T, BM, BN, KT, WM, WN, RES_PRE, GLDS, NS, SEG2, LN, BUFX>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     return mic_prof_close(rec, s);
 }
 
@@ -569,6 +628,8 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
         return e ? atoi(e) : 1;
     }();
     // residual prefetch variants: bf16 residual with vector-aligned rows, short K (memory-bound layers)
+    const bool no_bufx = getenv("MIC_IGEMM_NO_BUFX") != nullptr;  // comparison runs: the pointer form everywhere
+    const bool bufx = !no_bufx && !a.in2 && igemm_fits_buffers(a, (int)sizeof(T));
     if (res_pre && a.res && a.res_dtype == MIC_BF16 && a.vec_ok && a.N % 8 == 0 && a.K <= 128 * res_pre) {
         if (v == 0) return launch<T, 128, 128, 1, 2, 2, true>(a, s, flops);
     }
@@ -598,6 +659,15 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
             case 1: return launch<T, 128, 128, 2, 2, 2, false, true, 4>(a, s, flops);
             case 3: return launch<T, 128, 64, 2, 2, 2, false, true, 4>(a, s, flops);
             case 8: return launch<T, 128, 64, 1, 2, 2, false, true, 6>(a, s, flops);
+            default: break;
+        }
+    }
+    // measured on the ResNet-50 layers at batch 256: 3-5 % on the one-sub-tile stages, a loss with two sub-tiles per stage
+    // (the tap position is then per thread) and with the residual prefetch
+    if (bufx) {
+        switch (v) {
+            case 0: return launch<T, 128, 128, 1, 2, 2, false, false, 2, false, false, true>(a, s, flops);
+            case 8: return launch<T, 128, 64, 1, 2, 2, false, false, 2, false, false, true>(a, s, flops);
             default: break;
         }
     }

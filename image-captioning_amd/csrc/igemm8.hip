@@ -351,11 +351,6 @@ template <bool SEG2, int DBG = 0> __global__ __launch_bounds__(512) void igemm8_
     }
 }
 
-// bytes of the tensor a convolution reads, as far as its descriptor says: the last image's last tap's last channel
-long long extent_bytes(long long images, long long img_stride, long long rows, long long row_stride, long long cols, long long pix_stride, int run) {
-    return ((images - 1) * img_stride + (rows - 1) * row_stride + (cols - 1) * pix_stride + run) * 2;
-}
-
 }  // namespace
 
 bool mic_igemm8_supported(const IgemmArgs& a) {
@@ -363,18 +358,7 @@ bool mic_igemm8_supported(const IgemmArgs& a) {
     // tap or the boundary between the two K segments, no LayerNorm epilogue; 32-bit byte offsets into tensors of less than
     // 2 GiB and one validity bit per tap
     if (!(a.N % 256 == 0 && a.Kt % 64 == 0 && a.K % 64 == 0 && a.run % 64 == 0 && !a.ln_g)) return false;
-    if (a.K / a.run > 31) return false;
-    const long long lim = (1ll << 31) - (1 << 20);
-    const long long images = (a.M + a.OHW - 1) / a.OHW;
-    if (extent_bytes(images, a.img_stride, a.IH, a.row_stride, a.IW, a.pix_stride, a.run) > lim) return false;
-    if ((long long)((a.N + 127) / 128 * 128) * a.Kt * 2 > lim) return false;
-    if (a.in2) {
-        const int oh = a.OHW / a.OW;
-        if (extent_bytes(images, a.img_stride2, (long long)(oh - 1) * a.stride2 + 1, a.row_stride2, (long long)(a.OW - 1) * a.stride2 + 1,
-                         a.pix_stride2, a.K2) > lim)
-            return false;
-    }
-    return true;
+    return igemm_fits_buffers(a, 2);
 }
 
 extern "C" int64_t mic_conv2d_scratch_bytes(void) { return (int64_t)COUNTER_BYTES + 256ll * SLAB; }

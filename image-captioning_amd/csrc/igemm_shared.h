@@ -178,6 +178,28 @@ template <bool RES_PRE> __device__ __forceinline__ void igemm_finish_chunk(const
 
 }  // namespace
 
+// Whether every operand of the layer can be addressed by a 32-bit byte offset into a 2 GiB buffer descriptor with one
+// validity bit per tap: tensors below 2 GiB as far as the descriptor says (the last image's last tap's last channel), at
+// most 31 taps.
+static inline long long igemm_extent_bytes(long long images, long long img_stride, long long rows, long long row_stride, long long cols,
+                                           long long pix_stride, int run, int elem) {
+    return ((images - 1) * img_stride + (rows - 1) * row_stride + (cols - 1) * pix_stride + run) * elem;
+}
+static inline bool igemm_fits_buffers(const IgemmArgs& a, int elem) {
+    if (a.K / a.run > 31) return false;
+    const long long lim = (1ll << 31) - (1 << 20);
+    const long long images = (a.M + a.OHW - 1) / a.OHW;
+    if (igemm_extent_bytes(images, a.img_stride, a.IH, a.row_stride, a.IW, a.pix_stride, a.run, elem) > lim) return false;
+    if ((long long)((a.N + 127) / 128 * 128) * a.Kt * elem > lim) return false;
+    if (a.in2) {
+        const int oh = a.OHW / a.OW;
+        if (igemm_extent_bytes(images, a.img_stride2, (long long)(oh - 1) * a.stride2 + 1, a.row_stride2, (long long)(a.OW - 1) * a.stride2 + 1,
+                               a.pix_stride2, a.K2, elem) > lim)
+            return false;
+    }
+    return true;
+}
+
 // the eight-phase 256 x 256 bf16 variant (igemm8.hip): whether it takes the problem, and its launch
 bool mic_igemm8_supported(const IgemmArgs& a);
 int mic_igemm8_splitk(const IgemmArgs& a);  // slices per tile the launch would use (1: no split)

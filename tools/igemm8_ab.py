@@ -18,6 +18,8 @@ SHAPES = {  # name: B, H, Cin, Cout, k, stride, residual
     "s2c3": (256, 14, 256, 1024, 1, 1, True), "s3c1a": (256, 14, 1024, 512, 1, 1, False), "s3c2": (256, 7, 512, 512, 3, 1, False),
     "s3ds": (256, 14, 1024, 2048, 1, 2, False), "s3c1": (256, 7, 2048, 512, 1, 1, False), "s3c3": (256, 7, 512, 2048, 1, 1, True),
     "s2c1a": (256, 28, 512, 256, 1, 1, False), "s1c2": (256, 28, 128, 128, 3, 1, False), "g4k": (1, 64, 4096, 4096, 1, 1, False),
+    "s1c1": (256, 28, 512, 128, 1, 1, False), "s0c1": (256, 56, 256, 64, 1, 1, False), "s1ds": (256, 56, 256, 512, 1, 2, False),
+    "s1c3": (256, 28, 128, 512, 1, 1, True), "s0c2": (256, 56, 64, 64, 3, 1, False), "s0c3": (256, 56, 64, 256, 1, 1, True),
     "tiny": (1, 16, 64, 256, 1, 1, False), "tiny196": (196, 16, 64, 256, 1, 1, False),
     "g8k": (4, 64 * 0 + 45, 8192, 8192, 1, 1, False), "gsk": (16, 64, 2304, 256, 1, 1, False),
 }
