@@ -142,7 +142,7 @@ def measured_traffic():
     """HBM bytes per launch of the 128-row-tile bf16 igemm kernels on this workload, from the committed
     rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs of this script; a live
     run cannot collect hardware counters on itself).  None when the summary file is absent."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return round(json.load(f)["igemm_bf16_128row_tiles"]["hbm_bytes_per_launch"]), name

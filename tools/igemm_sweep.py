@@ -43,7 +43,9 @@ def run(desc, iters=10):
 
 
 def main():
+    global SCRATCH
     dt = torch.bfloat16
+    SCRATCH = torch.zeros(int(L.lib.mic_conv2d_scratch_bytes()), dtype=torch.uint8, device=DEV)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     tot = 0.0
     seen = {}
@@ -71,6 +73,7 @@ def main():
             d.in_img_stride, d.in_row_stride, d.in_pix_stride = IH * IW * cpix, IW * cpix, cpix
             d.kw_taps, d.run, d.stride, d.pad_h, d.pad_w = kw, run_, stride, pad, pad
             d.ldc, d.ld_res, d.relu = cout, cout, 1
+            d.scratch, d.scratch_bytes = SCRATCH.data_ptr(), SCRATCH.numel()  # as in the trunk: late layers may split K
             us = run(d)
             seen[key] = us
             del x, w, res, out

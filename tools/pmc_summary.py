@@ -26,7 +26,7 @@ def counters(d):
 
 
 def conv_launch(name):
-    return ("igemm_kernelIDF16b" in name and ("Li128ELi" in name or "Li256ELi" in name)) or "fused_block_kernel" in name or "stem_pool_kernel" in name
+    return ("igemm_kernelIDF16b" in name and ("Li128ELi" in name or "Li256ELi" in name)) or "igemm8_kernel" in name or "fused_block_kernel" in name or "stem_pool_kernel" in name
 
 
 def traffic(fetch_dir, write_dir, out, calls):
