@@ -119,18 +119,31 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) 
             x_w[i] = ow - 1;
         }
         const bf16_t* w_src = a.w2 + (long long)row0 * (9 * C) + q_own * 8;
-        int kh = 0, kw = 0, c0 = 0;
+        int kw = 0, c0 = 0;
         u32x4 xr[2], wr[WC1];
+        // Activation rows through a buffer descriptor at 32-bit byte offsets: bit 31 of the offset (a tap in the padding, a row
+        // past M; an offset that wrapped below zero has it anyway) makes the hardware return zeros without touching memory, so
+        // a load costs one add and two bit operations instead of clamps, a 64-bit multiply-add and four selects.
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.t1), (short)0, (int)0x80000000u, 0x00020000);
+        unsigned bx_off[2], bx_bad[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bx_off[i] = (unsigned)((x_img[i] + ((long long)x_h[i] * a.IW + x_w[i]) * C) * 2);
+            unsigned bad = x_ok[i] ? 0u : 0xffffffffu;
+#pragma unroll
+            for (int th = 0; th < 3; ++th)
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw)
+                    if (!((unsigned)(x_h[i] + th) < (unsigned)a.IH && (unsigned)(x_w[i] + tw) < (unsigned)a.IW)) bad |= 1u << (th * 3 + tw);
+            bx_bad[i] = bad;
+        }
+        unsigned tap = 0, tapb = 0;
+        const unsigned rowb = (unsigned)a.IW * C * 2u, pixb = C * 2u;
         auto load_stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                // unconditional load from a clamped (always valid) pixel, zeroed afterwards when the tap falls into the
-                // padding or the row is past M: a load under a condition would be branched around and waited for at once
-                const int ih = x_h[i] + kh, iw = x_w[i] + kw;
-                const bool ok = x_ok[i] && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
-                const int ihc = min(max(ih, 0), a.IH - 1), iwc = min(max(iw, 0), a.IW - 1);
-                const u32x4 v = *reinterpret_cast<const u32x4*>(a.t1 + x_img[i] + ((long long)ihc * a.IW + iwc) * C + c0);
-                xr[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+                const unsigned off = (bx_off[i] + tapb + (unsigned)c0 * 2u) | (__builtin_amdgcn_ubfe(bx_bad[i], tap, 1) << 31);
+                xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < WC1; ++i) wr[i] = *reinterpret_cast<const u32x4*>(w_src + (long long)i * 64 * (9 * C));
@@ -138,7 +151,9 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) 
             c0 += 32;
             if (c0 == C) {
                 c0 = 0;
-                if (++kw == 3) { kw = 0; ++kh; }
+                ++tap;
+                tapb += pixb;
+                if (++kw == 3) { kw = 0; tapb += rowb - 3u * pixb; }
             }
         };
         auto store_stage = [&](int buf) __attribute__((always_inline)) {
@@ -406,6 +421,7 @@ extern "C" int mic_bottleneck_fused(const mic_fused_block_desc* d, void* stream)
                   "mic_bottleneck_fused: an identity block takes res (CS = 0), a shortcut block xs with a supported CS (got CS=%d)", d->CS);
     MIC_ARG_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && (int64_t)d->B * d->H * d->W < (1ll << 31), "mic_bottleneck_fused: bad geometry %dx%dx%d",
                   d->B, d->H, d->W);
+    MIC_ARG_CHECK((int64_t)d->B * d->H * d->W * d->C * 2 < (1ll << 31) - (1 << 20), "mic_bottleneck_fused: t1 must stay below 2 GiB (32-bit byte offsets)");
     MIC_ARG_CHECK(d->C2 == 0 || (d->w1n && d->b1n && d->t1n), "mic_bottleneck_fused: the fused next convolution needs w1n, b1n and t1n");
     MIC_ARG_CHECK(d->w2_rows >= 128 && d->w3_rows >= 4 * d->C && (d->C2 == 0 || d->w1n_rows >= 128),
                   "mic_bottleneck_fused: weight matrices shorter than the kernel reads (w2 %d rows, w3 %d, w1n %d)", d->w2_rows, d->w3_rows,
