@@ -50,10 +50,12 @@ struct FusedAttnArgs {
 // the workgroup, the folded cross keys / values re-requested per group (from L2 after the first).  The group count is a
 // compile-time constant and the loop over groups fully unrolled: a real loop makes the compiler hoist every
 // group-independent value out of it and keep it alive across the whole kernel, which spills.
-template <typename T, int RG, int HEADS, int NG>
+// PPW: cached positions per wave and row, 8 * PPW positions over the waves (4: up to 32 positions, 6: up to 48).  With 6 the
+// folded values of a wave's last three positions are requested only once its keys have been consumed (their registers).
+template <typename T, int RG, int HEADS, int NG, int PPW = 4>
 __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) {
     constexpr int VEC = Vec16<T>::N, H = 64 * VEC, PARTS = H / 128, SP = 64, NW = 8, NT = 64 * NW;
-    constexpr int PPW = 32 / NW;                  // cached positions per wave and row: 32 positions over the waves
+    constexpr int PPE = PPW == 4 ? 4 : 3, PPL = PPW - PPE;  // positions whose values are requested up front / late
     constexpr int NJ = RG * PPW, NJP = pow2_at_least(NJ);  // (row, position) pairs per wave
     constexpr int NI = 64 / NW, NX = NI * HEADS;  // image tokens per wave: up to 64 over the waves
     constexpr int F4 = H / 4, NRV = (RG * F4 + NT - 1) / NT;
@@ -120,14 +122,16 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
                 srow[j] = p < t ? got : own;  // entries at and beyond t are not ancestry yet
             }
         }
-        Vec16<T> kreg[NJ], vreg[NJ][HEADS];
+        Vec16<T> kreg[NJ], vreg[RG * PPE][HEADS];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int p = wave + NW * (j % PPW);
+            const int q = j % PPW, p = wave + NW * q;
             const long long cell = (long long)srow[j] * a.t_cap + (p < t ? p : 0);
             kreg[j] = ld16(kc + cell * H + lc);
+            if (q < PPE) {
 #pragma unroll
-            for (int h = 0; h < HEADS; ++h) vreg[j][h] = ld16(vc + (cell * HEADS + h) * H + lc);
+                for (int h = 0; h < HEADS; ++h) vreg[(j / PPW) * PPE + q][h] = ld16(vc + (cell * HEADS + h) * H + lc);
+            }
         }
         // the new position of row w, by wave w: the fresh projection rounded through T, exactly what the cache will hold
         Vec16<T> knew, vnew[HEADS];
@@ -197,7 +201,18 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
             v = group_sum_down<LPH>(v);
             if ((lane & (LPH - 1)) == 0) sc[(wave * HEADS + hl) * SP + t] = v;
         }
-        // folded cross keys (and their constants), requested once the self-attention keys have been consumed
+        // the folded values of the late positions, then the folded cross keys (and their constants): requested once the
+        // self-attention keys have been consumed
+        Vec16<T> vlate[PPL > 0 ? RG * PPL : 1][HEADS];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = j % PPW, p = wave + NW * q;
+            if (q >= PPE) {
+                const long long cell = (long long)srow[j] * a.t_cap + (p < t ? p : 0);
+#pragma unroll
+                for (int h = 0; h < HEADS; ++h) vlate[(j / PPW) * PPL + q - PPE][h] = ld16(vc + (cell * HEADS + h) * H + lc);
+            }
+        }
         Vec16<T> kx[NI][HEADS];
         float cx[NI][HEADS];
 #pragma unroll
@@ -230,7 +245,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
                 for (int h = 0; h < HEADS; ++h) {
                     // a masked pair was loaded from a cell nothing has written yet: its bytes are selected away, not
                     // multiplied by a zero weight (0 * NaN is NaN, and a cache need not be zero-filled)
-                    const uint4 bits = on ? __builtin_bit_cast(uint4, vreg[j][h]) : make_uint4(0u, 0u, 0u, 0u);
+                    const Vec16<T>& held = jj < PPE ? vreg[rr * PPE + jj][h] : vlate[PPL > 0 ? rr * PPL + jj - PPE : 0][h];
+                    const uint4 bits = on ? __builtin_bit_cast(uint4, held) : make_uint4(0u, 0u, 0u, 0u);
                     const Vec16<T> val = __builtin_bit_cast(Vec16<T>, bits);
                     const float wgt = on ? sc[(rr * HEADS + h) * SP + p] : 0.f;
 #pragma unroll
@@ -385,13 +401,16 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const FusedAttnArgs a) 
     }
 }
 
-template <typename T, int RG, int HEADS, int NG> int launch_fused_attn(const FusedAttnArgs& a, hipStream_t s) {
+template <typename T, int RG, int HEADS, int NG, int PPW = 4> int launch_fused_attn_p(const FusedAttnArgs& a, hipStream_t s) {
     constexpr int H = 64 * Vec16<T>::N;
     const size_t lds = sizeof(float) * ((size_t)3 * RG * H + RG * HEADS * 64 + 8 * RG * (size_t)H + 3 * H);
     static std::atomic<uint64_t> granted{0};  // one bit per device; lanes call from several host threads
-    MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&attn_fused_kernel<T, RG, HEADS, NG>), 150 * 1024, granted));
-    MIC_LAUNCH((attn_fused_kernel<T, RG, HEADS, NG>), dim3(a.N / a.R), dim3(512), lds, s, a);
+    MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&attn_fused_kernel<T, RG, HEADS, NG, PPW>), 150 * 1024, granted));
+    MIC_LAUNCH((attn_fused_kernel<T, RG, HEADS, NG, PPW>), dim3(a.N / a.R), dim3(512), lds, s, a);
     return 0;
+}
+template <typename T, int RG, int HEADS, int NG> int launch_fused_attn(const FusedAttnArgs& a, hipStream_t s) {
+    return a.t_cap <= 32 ? launch_fused_attn_p<T, RG, HEADS, NG, 4>(a, s) : launch_fused_attn_p<T, RG, HEADS, NG, 6>(a, s);
 }
 
 template <typename T, int HEADS> int dispatch_fused_attn(const FusedAttnArgs& a, hipStream_t s) {
@@ -409,7 +428,7 @@ extern "C" int mic_attn_fused_supported(int dtype, int H, int heads, int S, int 
     if (dtype != MIC_F32 && dtype != MIC_BF16) return 0;
     const int vec = 16 / (int)mic_dtype_size(dtype);
     return H == 64 * vec && (heads == 1 || heads == 2) && S >= 1 && S <= 64 && rows_per_image >= 1 && rows_per_image <= MIC_MAX_BEAM &&
-           t_cap >= 1 && t_cap <= 32;
+           t_cap >= 1 && t_cap <= 48;
 }
 
 extern "C" int mic_attn_fused(const mic_attn_fused_desc* d, void* stream) {

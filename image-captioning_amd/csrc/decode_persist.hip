@@ -505,10 +505,12 @@ template <typename T> __device__ __forceinline__ Vec16<T> ld16s(const T* p) {
 }
 
 // ---- attention phase ------------------------------------------------------------------------------------------
-template <typename T, int RG, int HEADS> struct AttnPre {
-    static constexpr int PPW = 32 / NW, NJ = RG * PPW;
+// PPW: cached positions per wave and row (4: up to 32 positions over the 8 waves, 6: up to 48).  With 6 the folded values of
+// a wave's last three positions are requested only once its keys have been consumed (their registers).
+template <typename T, int RG, int HEADS, int PPW> struct AttnPre {
+    static constexpr int NJ = RG * PPW, PPE = PPW == 4 ? 4 : 3, PPL = PPW - PPE;
     int srow[NJ];  // wave-uniform: the row whose cache holds position p of this wave's pair
-    Vec16<T> kreg[NJ], vreg[NJ][HEADS];
+    Vec16<T> kreg[NJ], vreg[RG * PPE][HEADS];
 };
 
 struct AttnIO {
@@ -524,9 +526,9 @@ struct AttnIO {
 
 // cache rows of this wave's (row, position) pairs: ancestry, then keys and folded values.  Nothing here was written
 // by another workgroup of this launch: the cache cells of earlier positions and the ancestry table come from earlier launches.
-template <typename T, int RG, int HEADS>
-__device__ __forceinline__ void attn_ancestry(AttnPre<T, RG, HEADS>& pre, const int32_t* anc, long long n0, int rn, int t, int t_cap, int wave) {
-    constexpr int PPW = 32 / NW, NJ = RG * PPW;
+template <typename T, int RG, int HEADS, int PPW>
+__device__ __forceinline__ void attn_ancestry(AttnPre<T, RG, HEADS, PPW>& pre, const int32_t* anc, long long n0, int rn, int t, int t_cap, int wave) {
+    constexpr int NJ = RG * PPW;
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         const int rr = jj / PPW, p = wave + NW * (jj % PPW);
@@ -538,29 +540,31 @@ __device__ __forceinline__ void attn_ancestry(AttnPre<T, RG, HEADS>& pre, const 
         }
     }
 }
-template <typename T, int RG, int HEADS>
-__device__ __forceinline__ void attn_prefetch(AttnPre<T, RG, HEADS>& pre, const PLayer& ly, int t, int t_cap, int wave, int lane) {
-    constexpr int VEC = Vec16<T>::N, H = 64 * VEC, PPW = 32 / NW, NJ = RG * PPW;
+template <typename T, int RG, int HEADS, int PPW>
+__device__ __forceinline__ void attn_prefetch(AttnPre<T, RG, HEADS, PPW>& pre, const PLayer& ly, int t, int t_cap, int wave, int lane) {
+    constexpr int VEC = Vec16<T>::N, H = 64 * VEC, NJ = RG * PPW, PPE = AttnPre<T, RG, HEADS, PPW>::PPE;
     const int lc = lane * VEC;
     const T* kc = (const T*)ly.kcache;
     const T* vc = (const T*)ly.vfcache;
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
-        const int p = wave + NW * (jj % PPW);
+        const int q = jj % PPW, p = wave + NW * q;
         const long long cell = (long long)pre.srow[jj] * t_cap + (p < t ? p : 0);
         pre.kreg[jj] = ld16s(kc + cell * H + lc);
+        if (q < PPE) {
 #pragma unroll
-        for (int h = 0; h < HEADS; ++h) pre.vreg[jj][h] = ld16s(vc + (cell * HEADS + h) * H + lc);
+            for (int h = 0; h < HEADS; ++h) pre.vreg[(jj / PPW) * PPE + q][h] = ld16s(vc + (cell * HEADS + h) * H + lc);
+        }
     }
 }
 
 // Both attention sub-layers of image b (rows n0 .. n0 + rn): attn_fused_kernel with its exchanged operands read
 // through write-through-aware loads and its outputs stored write-through.
-template <typename T, int RG, int HEADS>
-__device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const AttnIO& io, const PLayer& ly, int b, long long n0, int rn, int S,
+template <typename T, int RG, int HEADS, int PPW>
+__device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS, PPW>& pre, const AttnIO& io, const PLayer& ly, int b, long long n0, int rn, int S,
                                           int t, int t_cap, float* smem, int wave, int lane) {
     constexpr int VEC = Vec16<T>::N, H = 64 * VEC, PARTS = H / 128, SP = 64;
-    constexpr int PPW = 32 / NW, NJ = RG * PPW, NJP = pow2_at_least(NJ);
+    constexpr int NJ = RG * PPW, NJP = pow2_at_least(NJ), PPE = AttnPre<T, RG, HEADS, PPW>::PPE, PPL = PPW - PPE;
     constexpr int NI = 64 / NW, NX = NI * HEADS;
     constexpr int F4 = H / 4, NRV = (RG * F4 + NT - 1) / NT;
     constexpr int QW = (2 + HEADS) * H, LPH = 64 / HEADS;
@@ -668,7 +672,19 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
         v = group_sum_down<LPH>(v);
         if ((lane & (LPH - 1)) == 0) sc[(wave * HEADS + hl) * SP + t] = v;
     }
-    // folded cross keys (and their constants), requested once the self-attention keys have been consumed
+    // the folded values of the late positions, then the folded cross keys (and their constants): requested once the
+    // self-attention keys have been consumed
+    Vec16<T> vlate[PPL > 0 ? RG * PPL : 1][HEADS];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int q = jj % PPW, p = wave + NW * q;
+        if (q >= PPE) {
+            const long long cell = (long long)pre.srow[jj] * t_cap + (p < t ? p : 0);
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h)
+                vlate[(jj / PPW) * PPL + q - PPE][h] = ld16s((const T*)ly.vfcache + (cell * HEADS + h) * H + lc);
+        }
+    }
     Vec16<T> kx[NI][HEADS];
     float cx[NI][HEADS];
 #pragma unroll
@@ -700,7 +716,8 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS>& pre, const Attn
 #pragma unroll
             for (int h = 0; h < HEADS; ++h) {
                 // a masked pair was loaded from a cell nothing has written yet: its bytes are selected away, not multiplied by zero
-                const uint4 bits = on ? __builtin_bit_cast(uint4, pre.vreg[jj][h]) : make_uint4(0u, 0u, 0u, 0u);
+                const Vec16<T>& held = q < PPE ? pre.vreg[rr * PPE + q][h] : vlate[PPL > 0 ? rr * PPL + q - PPE : 0][h];
+                const uint4 bits = on ? __builtin_bit_cast(uint4, held) : make_uint4(0u, 0u, 0u, 0u);
                 const Vec16<T> val = __builtin_bit_cast(Vec16<T>, bits);
                 const float wgt = on ? sc[(rr * HEADS + h) * SP + p] : 0.f;
 #pragma unroll
@@ -854,7 +871,7 @@ constexpr int LDS_HEAD = 16 + 2 * 48 * 2 * 4 + 2 * NW * 48 * 4;  // abort flag, 
 static_assert(LDS_HEAD % 16 == 0, "carve offsets stay 16-byte aligned");
 constexpr int LDS_BASES = MAX_SEAMS * 4;
 
-template <typename T, int RG, int HEADS>
+template <typename T, int RG, int HEADS, int PPW>
 __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs a) {
     constexpr int VEC = Vec16<T>::N, H = 64 * VEC, PARTS = H / 128, QW = (2 + HEADS) * H;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -935,12 +952,12 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
             int wave, lane;
             who(wave, lane);
             if (has_image) {
-                AttnPre<T, RG, HEADS> pre;
+                AttnPre<T, RG, HEADS, PPW> pre;
                 // the ancestry table is the previous launch's: read before the poll, so that the first wave, too, requests
                 // its cache rows the moment the seam is passed
-                attn_ancestry<T, RG, HEADS>(pre, a.anc, n0, R, a.t, a.t_cap, wave);
+                attn_ancestry<T, RG, HEADS, PPW>(pre, a.anc, n0, R, a.t, a.t_cap, wave);
                 seam_poll(seam, seam_idx - 1, wave);
-                attn_prefetch<T, RG, HEADS>(pre, ly, a.t, a.t_cap, wave, lane);
+                attn_prefetch<T, RG, HEADS, PPW>(pre, ly, a.t, a.t_cap, wave, lane);
                 if (!seam_join(seam)) return;
                 stamp(a.trace, 3 * seam_idx + 1);
                 AttnIO io{};
@@ -952,7 +969,7 @@ __global__ __launch_bounds__(NT, 2) void decode_persist_kernel(const PersistArgs
                 } else if (a.attn_mode == 2) {
                     io.attn_out = a.attn + ((long long)l * a.t_cap + a.t) * N * a.S; io.ld_attn = a.S;
                 }
-                attn_body<T, RG, HEADS>(pre, io, ly, b, n0, R, a.S, a.t, a.t_cap, reinterpret_cast<float*>(work), wave, lane);
+                attn_body<T, RG, HEADS, PPW>(pre, io, ly, b, n0, R, a.S, a.t, a.t_cap, reinterpret_cast<float*>(work), wave, lane);
             }
             plain = false; cs = ns; pg = ly.ln2_g; pb = ly.ln2_b;
             stamp(a.trace, 3 * seam_idx + 2);
@@ -1038,13 +1055,16 @@ template <typename T, int RG, int HEADS> size_t persist_lds_bytes() {
     return need;
 }
 
-template <typename T, int RG, int HEADS> int launch_persist(const PersistArgs& a, hipStream_t s) {
+template <typename T, int RG, int HEADS, int PPW> int launch_persist_p(const PersistArgs& a, hipStream_t s) {
     const size_t lds = persist_lds_bytes<T, RG, HEADS>();
     static std::atomic<uint64_t> granted{0};
-    MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&decode_persist_kernel<T, RG, HEADS>), 150 * 1024, granted));
+    MIC_TRY(mic_grant_dynamic_lds(reinterpret_cast<const void*>(&decode_persist_kernel<T, RG, HEADS, PPW>), 150 * 1024, granted));
     const int grid = 8 * CL * ((a.clusters + 7) / 8);
-    MIC_LAUNCH((decode_persist_kernel<T, RG, HEADS>), dim3(grid), dim3(NT), lds, s, a);
+    MIC_LAUNCH((decode_persist_kernel<T, RG, HEADS, PPW>), dim3(grid), dim3(NT), lds, s, a);
     return 0;
+}
+template <typename T, int RG, int HEADS> int launch_persist(const PersistArgs& a, hipStream_t s) {
+    return a.t_cap <= 32 ? launch_persist_p<T, RG, HEADS, 4>(a, s) : launch_persist_p<T, RG, HEADS, 6>(a, s);
 }
 
 template <typename T, int HEADS> int dispatch_persist(const PersistArgs& a, hipStream_t s) {
@@ -1062,7 +1082,7 @@ extern "C" int mic_tr_persist_supported(int dtype, int H, int heads, int layers,
     if (dtype != MIC_F32 && dtype != MIC_BF16) return 0;
     const int vec = 16 / (int)mic_dtype_size(dtype);
     if (H != 64 * vec || (heads != 1 && heads != 2) || S < 1 || S > 64 || rows_per_image < 1 || rows_per_image > 3) return 0;
-    if (t_cap < 1 || t_cap > 32 || layers < 1 || layers > MIC_MAX_LAYERS || 4 * layers > MAX_SEAMS) return 0;
+    if (t_cap < 1 || t_cap > 48 || layers < 1 || layers > MIC_MAX_LAYERS || 4 * layers > MAX_SEAMS) return 0;
     if (N < 1 || N % rows_per_image != 0) return 0;
     const int B = N / rows_per_image;
     return (B + CL - 1) / CL <= 16;  // one workgroup per CU: at most 16 clusters of 16 on the 256 CUs

@@ -341,7 +341,8 @@ int mic_cross_fold_c(const void* feats, const float* u, const float* c0, float* 
  * alias x_ln.raw) and, when stats_out != NULL, its row statistics per 128 columns (see mic_ln_ref).  attn_out as in
  * mic_cross_attn_step.  Same mathematics as the three launches it replaces (mic_self_attn_step, the output
  * projection, mic_cross_attn_folded), re-associated.  Supported (mic_attn_fused_supported): H == 1024 bytes / sizeof
- * element per row (512 bf16, 256 fp32), 1 or 2 heads, S <= 64, t_cap <= 32, up to MIC_MAX_BEAM rows per image. */
+ * element per row (512 bf16, 256 fp32), 1 or 2 heads, S <= 64, t_cap <= 48 (six cached positions per wave above 32, four
+ * up to it), up to MIC_MAX_BEAM rows per image. */
 typedef struct mic_attn_fused_desc {
     const float* qkvf;
     void *kcache, *vfcache;
@@ -636,7 +637,7 @@ int mic_tr_step(const mic_tr_decoder* dec, const mic_tr_workspace* ws, const int
  * loads) instead of ending a kernel after every sub-layer.  Same arithmetic as mic_tr_step, bit for bit.  Replaces the
  * loop body of models/transformer.py:602-609 / :492-507 like mic_tr_step.  Needs what the fused-attention step needs
  * (folded weights, qkvf, vfcache, stats) plus ws->sync; supported shapes: mic_tr_persist_supported (one 16-byte
- * element per lane per row, at most 2 heads, 3 rows per image, 32 cached positions, 256 images).  The launch assumes
+ * element per lane per row, at most 2 heads, 3 rows per image, 48 cached positions, 256 images).  The launch assumes
  * that its workgroups (one per CU, 16 per cluster) become resident together; every wait is bounded, and a wait
  * that runs out sets the error word ws->sync[mic_tr_persist_sync_words - 64] (non-zero = seam index + 0x100) and ends
  * the launch.  Do not run two of these launches concurrently on one GPU. */

@@ -54,17 +54,20 @@ def _run_steps(L, model, fn_name, B, R, S, T, feats, caps, anc, attn_mode):
     return out
 
 
-@pytest.mark.parametrize("dtype,H,heads,B,R", [
-    (torch.bfloat16, 512, 2, 256, 3),   # the benchmark's decode shape: 16 full clusters
-    (torch.bfloat16, 512, 2, 40, 3),    # ragged: the third cluster holds 8 images
-    (torch.bfloat16, 512, 2, 21, 1),    # one row per image (greedy / sampling)
-    (torch.bfloat16, 512, 1, 17, 2),
-    (torch.float32, 256, 2, 33, 3),
-    (torch.float32, 256, 1, 16, 1),
+@pytest.mark.parametrize("dtype,H,heads,B,R,T", [
+    (torch.bfloat16, 512, 2, 256, 3, 6),   # the benchmark's decode shape: 16 full clusters
+    (torch.bfloat16, 512, 2, 40, 3, 6),    # ragged: the third cluster holds 8 images
+    (torch.bfloat16, 512, 2, 21, 1, 6),    # one row per image (greedy / sampling)
+    (torch.bfloat16, 512, 1, 17, 2, 6),
+    (torch.float32, 256, 2, 33, 3, 6),
+    (torch.float32, 256, 1, 16, 1, 6),
+    (torch.bfloat16, 512, 2, 20, 3, 41),   # 41 cached positions (the reference's default max_caption_len = 40): six positions per wave
+    (torch.float32, 256, 2, 9, 2, 41),
+    (torch.bfloat16, 512, 1, 5, 1, 48),    # the most the fused attention takes
 ])
-def test_one_launch_step_equals_launch_per_sublayer_step(amd, dtype, H, heads, B, R):
+def test_one_launch_step_equals_launch_per_sublayer_step(amd, dtype, H, heads, B, R, T):
     L = amd._lib
-    V, Ly, PT, S, T = 500, 3, 16, 49, 6
+    V, Ly, PT, S = 500, 3, 48, 49
     sd = amd.weights.random_transformer_state(V, H, Ly, PT, seed=5)
     model = amd.transformer.ImageCaptioner(IdVocab(V), heads, dtype, encoder="none").load_state_dict(sd).to(DEV)
     g = torch.Generator().manual_seed(23)
@@ -76,6 +79,8 @@ def test_one_launch_step_equals_launch_per_sublayer_step(amd, dtype, H, heads, B
         img = torch.arange(N) // R
         anc = (img[:, None] * R + torch.randint(0, R, (N, T), generator=g)).to(torch.int32).to(DEV)
     for attn_mode in ((0, 1) if R > 1 else (0, 2)):
+        ws, _ = model._workspace(N, T, S, R, max(R, 1), attn_mode)
+        assert model.step_schedule(ws) == "persistent"
         ref = _run_steps(L, model, "mic_tr_step", B, R, S, T, feats, caps, anc, attn_mode)
         got = _run_steps(L, model, "mic_tr_step_persistent", B, R, S, T, feats, caps, anc, attn_mode)
         names = ["logits", "kcache", "vfcache", "y", "attn"]
@@ -108,6 +113,7 @@ def test_one_launch_step_refuses_unsupported_shapes(amd):
     L = amd._lib
     assert L.lib.mic_tr_persist_supported(1, 512, 2, 3, 49, 3, 31, 768) == 1
     assert L.lib.mic_tr_persist_supported(1, 512, 2, 3, 49, 5, 31, 1280) == 0    # five rows per image
-    assert L.lib.mic_tr_persist_supported(1, 512, 2, 3, 49, 3, 41, 768) == 0     # more than 32 cached positions
+    assert L.lib.mic_tr_persist_supported(1, 512, 2, 3, 49, 3, 41, 768) == 1     # the reference's default max_caption_len
+    assert L.lib.mic_tr_persist_supported(1, 512, 2, 3, 49, 3, 49, 768) == 0     # more than 48 cached positions
     assert L.lib.mic_tr_persist_supported(1, 512, 2, 3, 49, 3, 31, 3 * 300) == 0  # more images than 16 clusters hold
     assert L.lib.mic_tr_persist_supported(1, 256, 2, 3, 49, 3, 31, 768) == 0     # bf16 rows of 512 bytes
