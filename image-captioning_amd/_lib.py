@@ -57,7 +57,7 @@ class BeamTailDesc(C.Structure):
                 ("B", i32), ("K", i32), ("n_live_slots", i32), ("t", i32), ("t_cap", i32), ("eos_id", i32), ("finished_in_place", i32),
                 ("tok_emb", vp), ("pos_emb", vp), ("x", vp), ("xt", vp), ("ld_xt", i32), ("dtype", i32), ("H", i32), ("vocab", i32),
                 ("n_gather", i32), ("gather_src", vp * GATHER_MAX), ("gather_dst", vp * GATHER_MAX),
-                ("gather_row_bytes", i32 * GATHER_MAX), ("gather_stride_bytes", i32 * GATHER_MAX)]
+                ("gather_row_bytes", i32 * GATHER_MAX), ("gather_stride_bytes", i32 * GATHER_MAX), ("row_group_threads", i32)]
 
 
 class AttnFusedDesc(C.Structure):

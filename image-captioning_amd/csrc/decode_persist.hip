@@ -711,7 +711,7 @@ __device__ __forceinline__ void attn_body(AttnPre<T, RG, HEADS, PPW>& pre, const
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
-            const int jj = rr * PPW + q, p = wave + NW * q;
+            const int p = wave + NW * q;
             const bool on = rr < rn && p < t;
 #pragma unroll
             for (int h = 0; h < HEADS; ++h) {
@@ -1121,7 +1121,7 @@ int mic_tr_persist_launch(const mic_tr_decoder* dec, const mic_tr_workspace* ws,
     PersistArgs a{};
     if (tail) {
         MIC_ARG_CHECK(mic_tr_persist_tail_ok(dec, ws, tail->K, tail->V) && tail->B * tail->K == ws->N && tail->logits == ws->logits &&
-                          tail->ld == dec->vocab && tail->n_gather == 0,
+                          tail->ld == dec->vocab && tail->n_gather == 0 && (tail->K <= 2 || tail->row_group_threads == 128),
                       "mic_tr_step: the beam tail does not fit the one-launch step");
         MIC_TRY(tail_args_from_desc(tail, a.tail));
         a.has_tail = 1;

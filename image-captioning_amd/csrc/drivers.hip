@@ -721,6 +721,8 @@ extern "C" int mic_tr_beam_steps(const mic_tr_decoder* dec, const mic_tr_workspa
                 d.B = B; d.K = K; d.n_live_slots = t == 0 ? 1 : K; d.t = t; d.t_cap = ws->t_cap; d.eos_id = eos_id;
                 d.tok_emb = t + 1 < t1 ? dec->tok_emb : nullptr; d.pos_emb = dec->pos_emb; d.x = ws->x; d.xt = ws->xt; d.ld_xt = dec->H;
                 d.dtype = dec->dtype; d.H = dec->H; d.vocab = dec->vocab;
+                // the grouping of the one-launch step's tail phase, whichever schedule runs: every schedule rounds alike
+                d.row_group_threads = K >= 3 ? 128 : 0;
                 bool done = false;
                 MIC_TRY(mic_tr_step_impl(dec, ws, cur->seq, ws->t_cap, cur->anc, t, want_attn ? 1 : 0, t > t0, stream, true, &d, &done));
                 if (!done) MIC_TRY(mic_beam_tail_ex(&d, stream));

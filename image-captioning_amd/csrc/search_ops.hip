@@ -283,10 +283,7 @@ extern "C" int mic_logsoftmax_topk(const float* logits, int ld, int N, int V, in
     hipStream_t s = (hipStream_t)stream;
 #define MIC_TOPK_CASE(KK)                                                                                                  \
     case KK:                                                                                                               \
-        if (V <= 256 * 16 && KK >= 3) /* the row groups of the beam tail for three beams and more have 128 threads */     \
-            MIC_LAUNCH((logsoftmax_topk_reg_kernel<KK, 32, 128>), dim3(N), dim3(128), 0, s, logits, ld, V, inv_temp,       \
-                       rank_raw, out_val, out_idx, lse);                                                                   \
-        else if (V <= 256 * 16)                                                                                            \
+        if (V <= 256 * 16)                                                                                                 \
             MIC_LAUNCH((logsoftmax_topk_reg_kernel<KK, 16>), dim3(N), dim3(256), 0, s, logits, ld, V, inv_temp, rank_raw,  \
                        out_val, out_idx, lse);                                                                             \
         else                                                                                                               \
@@ -333,8 +330,15 @@ extern "C" int mic_beam_tail_ex(const mic_beam_tail_desc* d, void* stream) {
     MIC_TRY(tail_args_from_desc(d, a));
     const int B = d->B, K = d->K;
     hipStream_t s = (hipStream_t)stream;
-#define MIC_TAIL_CASE(KK) \
-    case KK: MIC_LAUNCH((beam_tail_kernel<KK, (KK <= 2 ? 256 : 128)>), dim3(B), dim3(KK <= 2 ? 256 * KK : 128 * KK), 0, s, a); break;
+    MIC_ARG_CHECK(d->row_group_threads == 0 || d->row_group_threads == 256 || d->row_group_threads == 128,
+                  "mic_beam_tail: row_group_threads is 0, 128 or 256");
+    MIC_ARG_CHECK(d->row_group_threads != 256 || K <= 4, "mic_beam_tail: 256 threads per row take at most four beams");
+    const bool narrow = d->row_group_threads == 128 || K > 4;
+#define MIC_TAIL_CASE(KK)                                                                                  \
+    case KK:                                                                                               \
+        if (narrow || KK > 4) MIC_LAUNCH((beam_tail_kernel<KK, 128>), dim3(B), dim3(128 * KK), 0, s, a);   \
+        else MIC_LAUNCH((beam_tail_kernel<KK, (KK <= 4 ? 256 : 128)>), dim3(B), dim3(256 * (KK <= 4 ? KK : 1)), 0, s, a); \
+        break;
     switch (K) {
         MIC_TAIL_CASE(1) MIC_TAIL_CASE(2) MIC_TAIL_CASE(3) MIC_TAIL_CASE(4)
         MIC_TAIL_CASE(5) MIC_TAIL_CASE(6) MIC_TAIL_CASE(7) MIC_TAIL_CASE(8)

@@ -461,6 +461,9 @@ typedef struct mic_beam_tail_desc {
     const void* gather_src[MIC_GATHER_MAX];
     void* gather_dst[MIC_GATHER_MAX];
     int32_t gather_row_bytes[MIC_GATHER_MAX], gather_stride_bytes[MIC_GATHER_MAX];
+    int32_t row_group_threads;   /* threads that share one row of logits: 0 = 256 for up to four beams and 128 above; 128 may be
+                                    asked for with three or four beams (the grouping of the one-launch decoder step's tail
+                                    phase: the log-sum-exp is then summed in that order, so both give the same bits) */
 } mic_beam_tail_desc;
 int mic_beam_tail_ex(const mic_beam_tail_desc* d, void* stream);
 
