@@ -61,7 +61,7 @@ struct alignas(8) B4 {
 // CS: channels of a stride-1 shortcut convolution folded into the expansion as a second K segment (the first block of a
 // stage: x' = relu([t2 | x] * [W3 | Wds]^T + b), no residual add); 0: the identity block with its residual tile.
 template <int C, int C2, int CS = 0>
-__global__ __launch_bounds__(256, 2) void fused_block_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256, (C == 64 && C2 == 64 && CS == 0) ? 3 : 2) void fused_block_kernel(const FusedArgs a) {
     constexpr int BM = 128, NB = 64, NOUT = 4 * C, NCH = NOUT / NB;
     constexpr int KT1 = 9 * C / 32;          // k-tiles of phase 1
     constexpr int KC = C + CS;               // K of phase 2
