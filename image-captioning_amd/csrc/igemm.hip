@@ -594,6 +594,8 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
         const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
         if (t256 >= 192 && a.N % 256 == 0 && a.Kt >= 1024) {
             v = 16;  // long K, enough 256x256 tiles for most CUs: half the operand bytes per FLOP
+        } else if (sizeof(T) == 2 && t256 >= 150 && t256 <= 256 && a.N % 256 == 0 && a.Kt >= 512) {
+            v = 15;  // one 256x256 tile for most CUs and no second round (the cross-K/V projection at batch 256: 23.1 against 25.5 us)
         } else if (t128 >= 192) {
             if (a.N <= 64) v = 8;
             else v = a.Kt >= 2048 ? 1 : 0;
