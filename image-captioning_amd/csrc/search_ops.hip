@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
     __shared__ SelShared sh;
     const long long base = (long long)blockIdx.x * a.K;
     if ((int)threadIdx.x < a.n_live_slots) slot_store(a, sh, threadIdx.x, slot_load(a, blockIdx.x, threadIdx.x));
-    beam_select_body(a, blockIdx.x, threadIdx.x, true, sh, a.top_val + base * a.K, a.top_idx + base * a.K, nullptr);
+    beam_select_body(a, blockIdx.x, threadIdx.x, true, sh, a.top_val + base * a.K, a.top_idx + base * a.K);
 }
 
 // One workgroup per image: G = min(K, 1024 / GW) rows at a time.

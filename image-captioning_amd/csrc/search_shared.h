@@ -91,9 +91,9 @@ __device__ __forceinline__ void slot_store(const BeamArgs& a, SelShared& sh, int
 // Selection for image b by one wave (`act`: this thread belongs to it, `lane` its lane); every thread of the
 // workgroup must call, the barriers are workgroup-wide; `wave` of `nwaves`: this thread's wave among those that call.  The caller has run slot_load / slot_store for the first
 // n_live_slots lanes of that wave (no barrier needed in between: the first one below publishes them).  tv / ti: the image's [K][K] top-K values and token ids
-// (global or LDS).  new_tok (LDS, [K], may be null): token appended to each surviving slot, -1 for a finished one.
+// (global or LDS).  Afterwards c_tok[win[r]] is the token appended to surviving slot r, -1 for a finished one.
 __device__ __forceinline__ void beam_select_body(const BeamArgs& a, int b, int lane, bool act, SelShared& sh, const float* tv,
-                                                 const int32_t* ti, int* new_tok, int wave = 0, int nwaves = 1) {
+                                                 const int32_t* ti, int wave = 0, int nwaves = 1) {
     const int K = a.K;
     const int base = b * K;
     const int ns = a.n_live_slots;
@@ -173,7 +173,6 @@ __device__ __forceinline__ void beam_select_body(const BeamArgs& a, int b, int l
             a.nxt.len[gd] = tok >= 0 ? len + 1 : len;
             if (tok >= 0) dseq[len] = tok;
             a.parent[gd] = gs;
-            if (new_tok) new_tok[r] = tok;
         }
     }
     if (act && lane == 0 && a.live_images) {
@@ -211,7 +210,6 @@ template <int K, int G, int NWG> struct TailShared {
     KV wbest[G][NWG];
     float tv[K * K];
     int32_t ti[K * K];
-    int new_tok[K];
 };
 
 // a logit another workgroup of the same launch wrote (HAND): read past the caches that are not coherent between compute units
@@ -233,7 +231,6 @@ __device__ __forceinline__ void beam_tail_body(const TailArgs& a, int img, int t
     auto& wbest = ts.wbest;
     float* tv = ts.tv;
     int32_t* ti = ts.ti;
-    int* new_tok = ts.new_tok;
     const int grp = tid / GW, gt = tid % GW, gw = gt >> 6, lane = tid & 63;
     // the beam state of the image's slots does not depend on the logits: requested now, parked in LDS after the top-K passes
     SlotState slot{};
@@ -322,13 +319,16 @@ __device__ __forceinline__ void beam_tail_body(const TailArgs& a, int img, int t
         }
     }
     if (tid < a.b.n_live_slots) slot_store(a.b, sh, tid, slot);
-    beam_select_body(a.b, img, lane, tid < 64, sh, tv, ti, new_tok, tid >> 6, G * NWG);
+    beam_select_body(a.b, img, lane, tid < 64, sh, tv, ti, tid >> 6, G * NWG);
     if (!a.tok_emb && a.n_gather == 0) return;
-    __syncthreads();
+    // What follows reads the ranking (win, c_slot, c_tok), final since the selection's last barrier: no barrier here, which
+    // would also wait for the row moves the first K waves have in flight (a chain of dependent round trips).  The work is
+    // dealt from the last thread down, so that it falls to the waves that move no row first.
+    const int rtid = GW * G - 1 - tid;
     // survivors' state rows: slot r of the next step continues slot c_slot[win[r]] of this one
     for (int g = 0; g < a.n_gather; ++g) {
         const int words = a.g_words[g];
-        for (int i = tid; i < K * words; i += GW * G) {
+        for (int i = rtid; i < K * words; i += GW * G) {
             const int r = i / words, w = i - r * words;
             const long long src_row = (long long)img * K + sh.c_slot[sh.win[r]], dst_row = (long long)img * K + r;
             a.g_dst[g][dst_row * a.g_stride[g] + w] = a.g_src[g][src_row * a.g_stride[g] + w];
@@ -336,9 +336,9 @@ __device__ __forceinline__ void beam_tail_body(const TailArgs& a, int img, int t
     }
     if (!a.tok_emb) return;
     const int hv = a.H >> 2, pos = a.b.t + 1;
-    for (int i = tid; i < K * hv; i += GW * G) {
+    for (int i = rtid; i < K * hv; i += GW * G) {
         const int r = i / hv, c = (i - r * hv) << 2;
-        int id = new_tok[r];
+        int id = sh.c_tok[sh.win[r]];  // -1: a finished beam
         id = id < 0 ? a.b.eos_id : id;  // a finished beam's row is never looked at again: any valid token serves
         id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
         float4 v = *reinterpret_cast<const float4*>(a.tok_emb + (long long)id * a.H + c);
