@@ -10,7 +10,7 @@
 // convolution to the next block's 1x1, so per block the HBM traffic is t1 + x in, x' + t1' out.
 //
 // One workgroup = 256 threads = 2x2 waves, 128 output pixels.
-//   phase 1: implicit-GEMM 3x3 (stride 1, pad 1), K = 9C in 64-byte k-tiles, register-staged double buffer;
+//   phase 1: implicit-GEMM 3x3 (stride 1, pad 1), K = 9C in 64-byte k-tiles, a ring of three direct-to-LDS stages;
 //   phase 2, per chunk of 64 output channels of the 4C: GEMM over K = C from the LDS image of t2 and a staged
 //            slice of W3; the epilogue adds bias and the residual slice (staged coalesced into the tile's LDS
 //            image beforehand), applies the ReLU, leaves the bf16 tile in LDS and copies it out in full rows;
@@ -52,6 +52,25 @@ __device__ __forceinline__ void mma(const u32x4_fwd& wf, const u32x4_fwd& xf, f3
 // memcpy through a private stack slot, which puts the register prefetch in scratch memory
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+// buffer descriptor over 2 GiB from p: raw 32-bit byte offsets, bit 31 of an offset = out of range = zeros
+__device__ __forceinline__ v4u_t make_srd(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    return v4u_t{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x80000000u, 0x00020000u};
+}
+// One buffer_load_dwordx4 ... lds: every lane fetches 16 bytes at its own byte offset into the buffer, the wave's 1 KiB
+// lands at LDS address `lds_base` + 16 * lane.  Inline assembly on purpose: a direct-to-LDS load the compiler can see makes
+// it drain the memory counter before the next LDS read; ordering here is the counted s_waitcnt + s_barrier of the loop.
+// M0 (the LDS base register) belongs to the compiler, so it is saved and restored around the instruction.
+__device__ __forceinline__ void blds16(unsigned voff, const v4u_t& srd, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_base), "s"(srd)
+                 : "memory");
+}
+
 struct alignas(8) B4 {
     bf16_t v[4];
 };
@@ -76,7 +95,8 @@ __global__ __launch_bounds__(256, (C == 64 && C2 == 64 && CS == 0) ? 3 : 2) void
     constexpr int A3 = 2 * BM * 64;                      // chunk tile [2][128 rows][64 B]
     constexpr int P23 = WA + WB + A3;
     constexpr int OUT3 = C2 > 0 ? (C2 / 32) * BM * 64 : 0;  // t1' tile [C2/32][128 rows][64 B], over the phase-2/3 region
-    constexpr int R0 = (2 * STAGE > P23 ? 2 * STAGE : P23) > OUT3 ? (2 * STAGE > P23 ? 2 * STAGE : P23) : OUT3;
+    constexpr int RING = 3 * STAGE;                      // phase 1 keeps three stages in flight
+    constexpr int R0 = (RING > P23 ? RING : P23) > OUT3 ? (RING > P23 ? RING : P23) : OUT3;
     constexpr int A2 = KT2 * BM * 64;                    // t2 tile [KT2][128 rows][64 B]
     __shared__ __attribute__((aligned(16))) unsigned char smem[R0 + A2];
     unsigned char* const sA2 = smem + R0;
@@ -104,50 +124,55 @@ __global__ __launch_bounds__(256, (C == 64 && C2 == 64 && CS == 0) ? 3 : 2) void
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc1[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     {
-        const int q_own = tid & 3, row0 = tid >> 2;  // 64 rows per pass of the workgroup's threads
-        long long x_img[2];
-        int x_h[2], x_w[2];
-        bool x_ok[2];
+        // Operand stages go global -> LDS directly (buffer_load ... lds, no register staging, no ds_write pass), three
+        // stages deep: the requests of k-tile st + 2 are issued while k-tile st is multiplied, one barrier per k-tile, and
+        // the memory counter is never drained inside the loop (a workgroup holds 4 waves and a compute unit 2 or 3
+        // workgroups: a k-tile's 8 or 16 MFMAs per wave are a fraction of one memory round trip).
+        // One wave instruction fills 1 KiB = 16 rows of a stage in lane order; the XOR swizzle of the LDS image is applied
+        // to the source chunk a lane fetches: lane l lands in row l >> 2, slot l & 3, which holds chunk slot ^ ((row >> 2) & 3).
+        const int q_src = (tid & 3) ^ ((lane >> 4) & 3), row0 = tid >> 2;  // rows row0 and row0 + 64 of the tile (and of W2)
+        // Activation rows through a buffer descriptor at 32-bit byte offsets: bit 31 of the offset (a tap in the padding, a row
+        // past M; an offset that wrapped below zero has it anyway) makes the hardware return zeros without touching memory.
+        const v4u_t srd_x = make_srd(a.t1), srd_w = make_srd(a.w2);
+        unsigned bx_off[2], bx_bad[2], bw_off[WC1];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int m = m0 + row0 + i * 64;
-            x_ok[i] = m < a.M;
-            m = x_ok[i] ? m : a.M - 1;
+            const bool ok = m < a.M;
+            m = ok ? m : a.M - 1;
             const int b = m / HW, r = m - b * HW, oh = r / a.IW, ow = r - oh * a.IW;
-            x_img[i] = (long long)b * HW * C + q_own * 8;
-            x_h[i] = oh - 1;
-            x_w[i] = ow - 1;
-        }
-        const bf16_t* w_src = a.w2 + (long long)row0 * (9 * C) + q_own * 8;
-        int kw = 0, c0 = 0;
-        u32x4 xr[2], wr[WC1];
-        // Activation rows through a buffer descriptor at 32-bit byte offsets: bit 31 of the offset (a tap in the padding, a row
-        // past M; an offset that wrapped below zero has it anyway) makes the hardware return zeros without touching memory, so
-        // a load costs one add and two bit operations instead of clamps, a 64-bit multiply-add and four selects.
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.t1), (short)0, (int)0x80000000u, 0x00020000);
-        unsigned bx_off[2], bx_bad[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bx_off[i] = (unsigned)((x_img[i] + ((long long)x_h[i] * a.IW + x_w[i]) * C) * 2);
-            unsigned bad = x_ok[i] ? 0u : 0xffffffffu;
+            const int xh = oh - 1, xw = ow - 1;
+            bx_off[i] = (unsigned)(((long long)b * HW * C + q_src * 8 + ((long long)xh * a.IW + xw) * C) * 2);
+            unsigned bad = ok ? 0u : 0xffffffffu;
 #pragma unroll
             for (int th = 0; th < 3; ++th)
 #pragma unroll
                 for (int tw = 0; tw < 3; ++tw)
-                    if (!((unsigned)(x_h[i] + th) < (unsigned)a.IH && (unsigned)(x_w[i] + tw) < (unsigned)a.IW)) bad |= 1u << (th * 3 + tw);
+                    if (!((unsigned)(xh + th) < (unsigned)a.IH && (unsigned)(xw + tw) < (unsigned)a.IW)) bad |= 1u << (th * 3 + tw);
             bx_bad[i] = bad;
         }
+#pragma unroll
+        for (int i = 0; i < WC1; ++i) bw_off[i] = (unsigned)(((row0 + i * 64) * (9 * C) + q_src * 8) * 2);
+        int kw = 0, c0 = 0;
         unsigned tap = 0, tapb = 0;
         const unsigned rowb = (unsigned)a.IW * C * 2u, pixb = C * 2u;
-        auto load_stage = [&]() __attribute__((always_inline)) {
+        const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+        const unsigned piece = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+        constexpr int NS = RING / STAGE;  // stages in flight; NL loads per thread and stage
+        constexpr int NL = 2 + WC1;
+        static_assert(NS * STAGE <= R0, "the phase-1 ring fits the region phases 2 and 3 reuse");
+        auto request = [&](int slot) __attribute__((always_inline)) {
+            const unsigned dst = piece + (unsigned)slot * STAGE;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const unsigned off = (bx_off[i] + tapb + (unsigned)c0 * 2u) | (__builtin_amdgcn_ubfe(bx_bad[i], tap, 1) << 31);
-                xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+                blds16(off, srd_x, dst + i * 64 * 64);
             }
 #pragma unroll
-            for (int i = 0; i < WC1; ++i) wr[i] = *reinterpret_cast<const u32x4*>(w_src + (long long)i * 64 * (9 * C));
-            w_src += 32;
+            for (int i = 0; i < WC1; ++i) {
+                blds16(bw_off[i], srd_w, dst + BM * 64 + i * 64 * 64);
+                bw_off[i] += 64;
+            }
             c0 += 32;
             if (c0 == C) {
                 c0 = 0;
@@ -156,25 +181,21 @@ __global__ __launch_bounds__(256, (C == 64 && C2 == 64 && CS == 0) ? 3 : 2) void
                 if (++kw == 3) { kw = 0; tapb += rowb - 3u * pixb; }
             }
         };
-        auto store_stage = [&](int buf) __attribute__((always_inline)) {
-            unsigned char* base = smem + buf * STAGE;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + lds_off(row0 + i * 64, q_own)) = xr[i];
-#pragma unroll
-            for (int i = 0; i < WC1; ++i) *reinterpret_cast<u32x4*>(base + BM * 64 + lds_off(row0 + i * 64, q_own)) = wr[i];
-        };
         int xf_off[4], wf_off[TN1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf_off[i] = lds_off(wm * 64 + i * 16 + fr, fq);
 #pragma unroll
         for (int j = 0; j < TN1; ++j) wf_off[j] = BM * 64 + lds_off(wn * (C / 2) + j * 16 + fr, fq);
-        load_stage();
-        store_stage(0);
-        __syncthreads();
-        int cur = 0;
-        for (int st = 0; st < ((a.dbg & 1) ? 1 : KT1); ++st) {
-            const bool more = st + 1 < KT1;
-            if (more) load_stage();
+        const int nst = (a.dbg & 1) ? 1 : KT1;
+        request(0);
+        request(1);
+        int cur = 0, nxt2 = 2;
+        for (int st = 0; st < nst; ++st) {
+            // k-tile st has landed for every thread (the next one may still be in flight); every wave is done reading
+            // k-tile st - 1, whose slot the requests below overwrite
+            if (st + 1 < KT1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (st + 2 < KT1) request(nxt2);
             const unsigned char* base = smem + cur * STAGE;
             u32x4 xf[4], wf[TN1];
 #pragma unroll
@@ -185,10 +206,10 @@ __global__ __launch_bounds__(256, (C == 64 && C2 == 64 && CS == 0) ? 3 : 2) void
             for (int j = 0; j < TN1; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mma(wf[j], xf[i], acc1[j][i]);
-            if (more) store_stage(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            nxt2 = nxt2 + 1 == NS ? 0 : nxt2 + 1;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (timing builds that cut the loop short leave requests in flight)
     }
 
     // ---------------- slices of chunk `nc`: W3 rows, W1n columns, residual ----------------
