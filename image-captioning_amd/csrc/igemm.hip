@@ -635,7 +635,7 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
     if (res_pre && a.res && a.res_dtype == MIC_BF16 && a.vec_ok && a.N % 8 == 0 && a.K <= 128 * res_pre) {
         if (v == 0) return launch<T, 128, 128, 1, 2, 2, true>(a, s, flops);
     }
-    static const int glds = [] {
+    const int glds = [] {  // read per launch: comparison runs switch it inside one process
         const char* e = getenv("MIC_IGEMM_GLDS");
         return e ? atoi(e) : 0;
     }();
