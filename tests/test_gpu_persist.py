@@ -36,8 +36,10 @@ def _run_steps(L, model, fn_name, B, R, S, T, feats, caps, anc, attn_mode):
     N = B * R
     ws, t = model._workspace(N, T, S, R, max(R, 1), attn_mode)
     assert "sync" in t, "the workspace did not get seam counters: shape not supported by the one-launch step?"
-    for k in ("kc", "vc", "vfc", "y", "stats"):
+    for k in ("vc", "y", "stats"):
         t[k].zero_()
+    for k in ("kc", "vfc"):  # cache cells no step has written hold NaN: both schedules must select masked positions away
+        t[k].fill_(float("nan"))
     if attn_mode:
         t["attn"].zero_()
     L.check(L.lib.mic_tr_cross_kv(C.byref(model.dec), C.byref(ws), feats.data_ptr(), L.stream_ptr()), "mic_tr_cross_kv")
