@@ -608,7 +608,8 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
     // (measured on the ResNet-50 layers at batch 256: stage 2 and 3 layers with K >= 1024)
     bool eight = false;
     if constexpr (sizeof(T) == 2) {
-        if (forced < 0 && a.Kt >= 1024 && mic_igemm8_supported(a)) {
+        // (two K segments: from 768 on, the stage-2 tail at 109 against 118 us)
+        if (forced < 0 && a.Kt >= (a.in2 ? 768 : 1024) && mic_igemm8_supported(a)) {
             const long long t256 = (long long)((a.M + 255) / 256) * (a.N / 256);
             eight = t256 >= 150 || mic_igemm8_splitk(a) * t256 >= 150;
         }

@@ -30,13 +30,18 @@ def layers(B=256):
     return out
 
 
-def run(desc, iters=10):
+def run(desc, iters=10, variant=-1):
+    def call():
+        if variant < 0:
+            L.check(L.lib.mic_conv2d(C.byref(desc), L.stream_ptr()))
+        else:
+            L.check(L.lib.mic_conv2d_variant(C.byref(desc), variant, L.stream_ptr()))
     for _ in range(2):
-        L.check(L.lib.mic_conv2d(C.byref(desc), L.stream_ptr()))
+        call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        L.check(L.lib.mic_conv2d(C.byref(desc), L.stream_ptr()))
+        call()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3  # us
@@ -182,10 +187,18 @@ def tails():
         d.ldc, d.relu = N, 1
         d.in2, d.K2, d.stride2 = x.data_ptr(), K2, st
         d.in2_img_stride, d.in2_row_stride, d.in2_pix_stride = h * h * K2, h * K2, K2
-        us = run(d)
+        scratch = torch.zeros(int(L.lib.mic_conv2d_scratch_bytes()), dtype=torch.uint8, device=DEV)
+        d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
         fl = 2.0 * M * N * (K1 + K2)
         by = 2.0 * (M * K1 + M * K2 + M * N)
-        print(f"s{si} tail M={M:8d} N={N:5d} K={K1}+{K2} {us:8.1f} us {fl / us / 1e6:7.1f} TF  ~{by / us / 1e6:5.2f} TB/s")
+        line = f"s{si} tail M={M:8d} N={N:5d} K={K1}+{K2}"
+        for v in (-1, 0, 11, 16, 18):  # the heuristic's pick, then the variants that take two K segments
+            try:
+                us = run(d, variant=v)
+            except L.MicError:
+                continue
+            line += f" | {v}: {us:7.1f} us {fl / us / 1e6:6.1f} TF ~{by / us / 1e6:4.2f} TB/s"
+        print(line)
         cin, h = 4 * wd, oh
 
 
