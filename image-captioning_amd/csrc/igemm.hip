@@ -597,11 +597,14 @@ template <typename T> int dispatch(IgemmArgs& a, hipStream_t s, double flops, in
         } else if (sizeof(T) == 2 && t256 >= 150 && t256 <= 256 && a.N % 256 == 0 && a.Kt >= 512) {
             v = 15;  // one 256x256 tile for most CUs and no second round (the cross-K/V projection at batch 256: 23.1 against 25.5 us)
         } else if (t128 >= 192) {
-            if (a.N <= 64) v = 8;
+            // fewer 128x128 tiles than CUs: half-width tiles put twice as many CUs to work (the ResNet-50 stage-2 layers at
+            // batch 64: 35 against 41 us)
+            if (a.N <= 64 || t128 < 256) v = 8;
             else v = a.Kt >= 2048 ? 1 : 0;
         } else {
             const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-            v = t64 > 256 ? 4 : 5;
+            // a long K pays for the deeper stage even with more tiles than CUs (stage-3 3x3 at batch 64: 39 against 52 us)
+            v = t64 > 256 && a.Kt < 2048 ? 4 : 5;
         }
     }
     // bf16, long K: the eight-phase 256 x 256 variant where it has a tile for most compute units, or can split K to get there

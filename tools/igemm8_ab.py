@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--shapes", default="s2c2,s2c1,s3c2,s3c1a,g4k")
+    ap.add_argument("--batch", type=int, default=0, help="images instead of each shape's own batch (256 for the ResNet layers)")
     ap.add_argument("configs", nargs="+")
     args = ap.parse_args()
     cfgs = []
@@ -41,6 +42,7 @@ def main():
     envs = sorted({k for _, _, e in cfgs for k in e})
     for name in args.shapes.split(","):
         B, H, Ci, Co, k, s, use_res = SHAPES[name]
+        B = args.batch or B
         p = 1 if k == 3 else 0
         OH = (H + 2 * p - k) // s + 1
         x = (torch.rand(B, H, H, Ci, device=DEV) * 2 - 1).to(torch.bfloat16)
