@@ -22,6 +22,11 @@ SHAPES = {  # name: B, H, Cin, Cout, k, stride, residual
     "s1c3": (256, 28, 128, 512, 1, 1, True), "s0c2": (256, 56, 64, 64, 3, 1, False), "s0c3": (256, 56, 64, 256, 1, 1, True),
     "s1b0c2": (256, 56, 128, 128, 3, 2, False), "s2b0c2": (256, 28, 256, 256, 3, 2, False), "s3b0c2": (256, 14, 512, 512, 3, 2, False),
     "ckv": (256, 7, 512, 1024, 1, 1, False),
+    # Swin-V2 GEMMs without the LayerNorm epilogue at batch 512: QKV and MLP-1 of the four stages
+    "w0qkv": (512, 56, 96, 288, 1, 1, False), "w0fc1": (512, 56, 96, 384, 1, 1, False),
+    "w1qkv": (512, 28, 192, 576, 1, 1, False), "w1fc1": (512, 28, 192, 768, 1, 1, False),
+    "w2qkv": (512, 14, 384, 1152, 1, 1, False), "w2fc1": (512, 14, 384, 1536, 1, 1, False),
+    "w3qkv": (512, 7, 768, 2304, 1, 1, False), "w3fc1": (512, 7, 768, 3072, 1, 1, False),
     "tiny": (1, 16, 64, 256, 1, 1, False), "tiny196": (196, 16, 64, 256, 1, 1, False),
     "g8k": (4, 64 * 0 + 45, 8192, 8192, 1, 1, False), "gsk": (16, 64, 2304, 256, 1, 1, False),
 }
