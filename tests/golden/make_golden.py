@@ -160,7 +160,7 @@ def transformer_fixtures(tr, Vocabulary):
     out.update(sd_to_np({k: v for k, v in model.state_dict().items() if not k.startswith("encoder.")}))
 
     g = torch.Generator().manual_seed(1)
-    # ---- per-module vectors ----
+    # ---- per-module vectors: each sub-module of the encoders and decoders on its own ----
     B, t, S = 3, 5, 49
     ids = torch.randint(4, V, (B, t), generator=g)
     x = torch.randn(B, t, H, generator=g)
