@@ -136,12 +136,12 @@ class LstmDecoder(C.Structure):
     _fields_ = [("dtype", i32), ("E", i32), ("Hd", i32), ("layers", i32), ("vocab", i32), ("kind", i32),
                 ("kpad", i32 * MAX_LAYERS), ("embed", vp), ("w", vp * MAX_LAYERS), ("b", vp * MAX_LAYERS),
                 ("ln_g", vp), ("ln_b", vp), ("out_w", vp), ("out_b", vp), ("out_k", i32),
-                ("wf", vp * MAX_LAYERS), ("out_wf", vp)]
+                ("wf", vp * MAX_LAYERS), ("out_wf", vp), ("wf_cell", vp * MAX_LAYERS), ("b_cell", vp * MAX_LAYERS)]
 
 
 class LstmWorkspace(C.Structure):
     _fields_ = [("N", i32), ("xh", vp * MAX_LAYERS), ("h", vp * MAX_LAYERS), ("c", vp * MAX_LAYERS),
-                ("gates", vp), ("hn", vp), ("hnt", vp), ("logits", vp), ("scratch", vp)]
+                ("gates", vp), ("hn", vp), ("hnt", vp), ("logits", vp), ("scratch", vp), ("hstage", vp * MAX_LAYERS)]
 
 
 P = C.POINTER
@@ -175,6 +175,7 @@ SIGNATURES = {
     "mic_pack_weight_frag": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mic_linear_skinny": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_linear_skinny_ex": (C.c_int, [C.POINTER(SkinnyDesc), vp]),
+    "mic_lstm_gates_cell": (C.c_int, [C.POINTER(SkinnyDesc), vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mic_linear_res_ln_supported": (C.c_int, [C.c_int]),
     "mic_linear_res_ln": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mic_self_attn_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -768,8 +768,18 @@ extern "C" int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_works
 // ---------------------------------------------------------------------------------------------
 namespace {
 // skip_embed: the input half of xh[0] already holds the embedding of this step's tokens (written by the previous step's tail)
+// whether layer l's cell can run in the epilogue of its gate GEMM: unit-major weights, a staging row for h', the
+// weight-streaming GEMM's row limit, and not the top layer of the intermediate model when that one's cell carries the LayerNorm
+bool lstm_cell_fusable(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, int l) {
+    static const bool off = getenv("MIC_NO_CELL_FUSE") != nullptr;  // comparison runs
+    if (off || !dec->wf_cell[l] || !dec->b_cell[l] || !ws->hstage[l] || ws->N > 2048) return false;
+    return !(l + 1 == dec->layers && dec->kind == 1 && mic_lstm_cell_ln_supported(dec->Hd));
+}
+
+// fuse_cell: the caller moves h' from ws->hstage[l] into the recurrent half of the next step's [x | h] rows (the beam tail's
+// gather); a step that leaves its state in place cannot fuse, because the gate GEMM is still reading those rows
 int lstm_step_impl(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, const int32_t* tokens, int ld_tok, int pos,
-                   const void* feat_t, int ld_feat, bool skip_embed, void* stream) {
+                   const void* feat_t, int ld_feat, bool skip_embed, void* stream, bool fuse_cell = false) {
     MIC_ARG_CHECK(dec && ws && (tokens || feat_t || skip_embed), "mic_lstm_step: null pointer");
     MIC_ARG_CHECK(dec->dtype == MIC_F32 || dec->dtype == MIC_BF16, "mic_lstm_step: bad dtype");
     MIC_ARG_CHECK(dec->layers >= 1 && dec->layers <= MIC_MAX_LAYERS && dec->E > 0 && dec->Hd > 0 && ws->N > 0, "mic_lstm_step: bad sizes");
@@ -787,11 +797,18 @@ int lstm_step_impl(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, co
     bool ln_done = false;
     for (int l = 0; l < L; ++l) {
         const int in_dim = l == 0 ? E : Hd;
-        MIC_TRY(proj(dt, dec->wf[l], ws->xh[l], dec->kpad[l], N, dec->kpad[l], dec->w[l], dec->b[l], ws->gates, MIC_F32, 4 * Hd, 4 * Hd, 0, s));
         void* up = nullptr;
         int ld_up = 0;
         if (l + 1 < L) { up = ws->xh[l + 1]; ld_up = dec->kpad[l + 1]; }
         else if (dec->kind == 0) { up = ws->hnt; ld_up = dec->out_k; }
+        if (fuse_cell && lstm_cell_fusable(dec, ws, l)) {
+            mic_skinny_desc d{};
+            d.x = ws->xh[l]; d.ld_x = dec->kpad[l]; d.wf = dec->wf_cell[l]; d.bias = dec->b_cell[l];
+            d.dtype = dt; d.out_dtype = MIC_F32; d.M = N; d.N = 4 * Hd; d.K = dec->kpad[l];
+            MIC_TRY(mic_lstm_gates_cell(&d, ws->c[l], ws->h[l], (char*)ws->hstage[l] + (size_t)in_dim * sz, dec->kpad[l], up, ld_up, Hd, s));
+            continue;
+        }
+        MIC_TRY(proj(dt, dec->wf[l], ws->xh[l], dec->kpad[l], N, dec->kpad[l], dec->w[l], dec->b[l], ws->gates, MIC_F32, 4 * Hd, 4 * Hd, 0, s));
         void* own = (char*)ws->xh[l] + (size_t)in_dim * sz;
         if (l + 1 == L && dec->kind == 1 && !no_cell_ln && mic_lstm_cell_ln_supported(Hd)) {
             MIC_TRY(mic_lstm_cell_ln(ws->gates, ws->c[l], ws->h[l], own, dec->kpad[l], dec->ln_g, dec->ln_b, ws->hn, ws->hnt, dec->out_k, dt, N,
@@ -843,7 +860,7 @@ extern "C" int mic_lstm_beam_steps(const mic_lstm_decoder* dec, const mic_lstm_w
             const mic_lstm_workspace* wn = &ws[(t + 1) & 1];
             const mic_beam_state* cur = &st[t & 1];
             const mic_beam_state* nxt = &st[(t + 1) & 1];
-            MIC_TRY(lstm_step_impl(dec, wc, cur->seq, t_cap, t, nullptr, 0, tail && t > t0, stream));
+            MIC_TRY(lstm_step_impl(dec, wc, cur->seq, t_cap, t, nullptr, 0, tail && t > t0, stream, tail));
             if (tail) {
                 mic_beam_tail_desc d{};
                 d.logits = wc->logits; d.ld = dec->vocab; d.V = dec->vocab; d.cur = cur; d.nxt = nxt; d.parent = parent;
@@ -856,7 +873,9 @@ extern "C" int mic_lstm_beam_steps(const mic_lstm_decoder* dec, const mic_lstm_w
                     const int in_dim = l == 0 ? dec->E : dec->Hd;
                     d.gather_src[2 * l] = wc->c[l]; d.gather_dst[2 * l] = wn->c[l];
                     d.gather_row_bytes[2 * l] = d.gather_stride_bytes[2 * l] = dec->Hd * 4;
-                    d.gather_src[2 * l + 1] = (const char*)wc->xh[l] + (size_t)in_dim * sz;
+                    // h': from the layer's own recurrent half, or from the staging rows when its cell ran in the gate GEMM
+                    const bool staged = lstm_cell_fusable(dec, wc, l);
+                    d.gather_src[2 * l + 1] = (const char*)(staged ? wc->hstage[l] : wc->xh[l]) + (size_t)in_dim * sz;
                     d.gather_dst[2 * l + 1] = (char*)wn->xh[l] + (size_t)in_dim * sz;
                     d.gather_row_bytes[2 * l + 1] = dec->Hd * sz; d.gather_stride_bytes[2 * l + 1] = dec->kpad[l] * sz;
                 }

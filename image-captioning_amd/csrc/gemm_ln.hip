@@ -191,7 +191,18 @@ struct SkinnyArgs {
     void* out;
     float* stats_out;
     int ld_x, ld_res, ldc, M, N, K, relu, out_dtype, col_blocks, xcd_rows;
+    // LSTM cell in the epilogue (cell_c != NULL): the N = 4 Hd columns are the gate pre-activations in unit-major order
+    // (column 4u + g: gate g of hidden unit u, g = input, forget, cell, output), so the four values a lane holds of one
+    // 16-column tile are the four gates of one unit.  c is updated in place, h' goes to cell_h (fp32) and, in T, to
+    // cell_t0 / cell_t1; nothing is written to `out`.
+    float* cell_c;
+    float* cell_h;
+    void* cell_t0;
+    void* cell_t1;
+    int cell_ld0, cell_ld1, cell_hd;
 };
+
+__device__ __forceinline__ float skinny_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // mean and 1/sqrt(var + eps) of one row from its per-part (mean, M2) pairs.  All parts are requested before any is used
 // (a loop with a runtime trip count would wait for each pair in turn: one memory round trip per part); parts past the
@@ -275,6 +286,14 @@ __global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : (MT == 1 && N
             }
         }
     }
+    float cprev[MT][TPW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int n = nb + j * 16 + q * 4, m = m0 + i * 16 + r;
+            cprev[i][j] = a.cell_c && n < a.N && m < a.M ? a.cell_c[(long long)m * a.cell_hd + (n >> 2)] : 0.f;
+        }
     if (tid < ROWS) {
         const int mr = m0 + tid < a.M ? m0 + tid : a.M - 1;
         if (a.xl.raw) merge_row_stats(a.xl, mr, rs_x[tid][0], rs_x[tid][1]);
@@ -353,6 +372,28 @@ __global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : (MT == 1 && N
                 v[i][j][e] = a.relu ? fmaxf(x, 0.f) : x;
             }
         }
+    }
+    if (a.cell_c) {
+        // the arithmetic of lstm_cell_kernel (decode_ops.hip) on the values that kernel would have read back from memory
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int n = nb + j * 16 + q * 4, u = n >> 2;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = m0 + i * 16 + r;
+                if (m >= a.M) continue;
+                const float ig = skinny_sigmoid(v[i][j][0]), fg = skinny_sigmoid(v[i][j][1]), gg = tanhf(v[i][j][2]), og = skinny_sigmoid(v[i][j][3]);
+                const float cn = fg * cprev[i][j] + ig * gg;
+                const float hn = og * tanhf(cn);
+                const long long ci = (long long)m * a.cell_hd + u;
+                a.cell_c[ci] = cn;
+                a.cell_h[ci] = hn;
+                if (a.cell_t0) ((T*)a.cell_t0)[(long long)m * a.cell_ld0 + u] = from_f32<T>(hn);
+                if (a.cell_t1) ((T*)a.cell_t1)[(long long)m * a.cell_ld1 + u] = from_f32<T>(hn);
+            }
+        }
+        return;
     }
     if (a.stats_out) {
         // per row: mean and centred sum of squares over this workgroup's valid columns
@@ -509,15 +550,42 @@ extern "C" int mic_pack_weight_frag(const void* w, void* out, int dtype, int N, 
     return 0;
 }
 
-extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) {
-    MIC_ARG_CHECK(d && d->wf && d->out && (d->x || d->x_ln.raw), "mic_linear_skinny: null pointer");
+namespace {
+struct CellOut {
+    float* c;
+    float* h;
+    void* t0;
+    void* t1;
+    int ld0, ld1, hd;
+};
+int skinny_impl(const mic_skinny_desc* d, const CellOut* cell, void* stream);
+}  // namespace
+
+extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) { return skinny_impl(d, nullptr, stream); }
+
+extern "C" int mic_lstm_gates_cell(const mic_skinny_desc* d, float* c, float* h, void* ht0, int ld0, void* ht1, int ld1, int Hd, void* stream) {
+    MIC_ARG_CHECK(d && c && h && Hd > 0 && d->N == 4 * Hd, "mic_lstm_gates_cell: c, h and N = 4 Hd columns are needed (N=%d, Hd=%d)", d ? d->N : 0, Hd);
+    MIC_ARG_CHECK(!d->relu && !d->res && !d->res_ln.raw && !d->stats_out, "mic_lstm_gates_cell: no activation, residual or statistics");
+    MIC_ARG_CHECK((!ht0 || ld0 >= Hd) && (!ht1 || ld1 >= Hd), "mic_lstm_gates_cell: ld0=%d / ld1=%d shorter than Hd=%d", ld0, ld1, Hd);
+    // the activation rows are read by every workgroup of the launch: h' must not land in them
+    const size_t esz = mic_dtype_size(d->dtype);
+    const char *x0 = (const char*)d->x, *x1 = x0 ? x0 + ((size_t)(d->M - 1) * d->ld_x + d->K) * esz : nullptr;
+    auto inside = [&](const void* p, int ld) { return p && x0 && (const char*)p + ((size_t)(d->M - 1) * ld + Hd) * esz > x0 && (const char*)p < x1; };
+    MIC_ARG_CHECK(!inside(ht0, ld0) && !inside(ht1, ld1), "mic_lstm_gates_cell: h' would overwrite the rows the launch is reading");
+    const CellOut cell{c, h, ht0, ht1, ld0, ld1, Hd};
+    return skinny_impl(d, &cell, stream);
+}
+
+namespace {
+int skinny_impl(const mic_skinny_desc* d, const CellOut* cell, void* stream) {
+    MIC_ARG_CHECK(d && d->wf && (d->out || cell) && (d->x || d->x_ln.raw), "mic_linear_skinny: null pointer");
     MIC_ARG_CHECK((d->dtype == MIC_F32 || d->dtype == MIC_BF16) && (d->out_dtype == MIC_F32 || d->out_dtype == MIC_BF16),
                   "mic_linear_skinny: bad dtype");
     const int epr = 64 / (int)mic_dtype_size(d->dtype);
-    MIC_ARG_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->K % epr == 0 && d->ldc >= d->N, "mic_linear_skinny: bad sizes M=%d N=%d K=%d ldc=%d",
-                  d->M, d->N, d->K, d->ldc);
+    MIC_ARG_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->K % epr == 0, "mic_linear_skinny: bad sizes M=%d N=%d K=%d", d->M, d->N, d->K);
     MIC_ARG_CHECK(d->x_ln.raw || (d->ld_x >= d->K && d->ld_x % (epr / 4) == 0 && ((uintptr_t)d->x & 15) == 0), "mic_linear_skinny: bad x / ld_x=%d", d->ld_x);
     MIC_ARG_CHECK(((uintptr_t)d->wf & 15) == 0 && ((uintptr_t)d->out & 15) == 0, "mic_linear_skinny: 16-byte alignment");
+    MIC_ARG_CHECK(cell || d->ldc >= d->N, "mic_linear_skinny: ldc=%d < N=%d", d->ldc, d->N);
     MIC_ARG_CHECK(!d->res || d->ld_res >= d->N, "mic_linear_skinny: ld_res=%d", d->ld_res);
     MIC_ARG_CHECK(!(d->stats_out && d->relu), "mic_linear_skinny: statistics of a ReLU output are not supported");
     MIC_TRY(check_ln_ref("mic_linear_skinny(x_ln)", d->x_ln, d->K));
@@ -527,6 +595,10 @@ extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) {
     a.xl = LnRef{d->x_ln.raw, d->x_ln.stats, d->x_ln.gamma, d->x_ln.beta, d->x_ln.ld, d->x_ln.parts, d->x_ln.width};
     a.rl = LnRef{d->res_ln.raw, d->res_ln.stats, d->res_ln.gamma, d->res_ln.beta, d->res_ln.ld, d->res_ln.parts, d->res_ln.width};
     a.ld_x = d->ld_x; a.ld_res = d->ld_res; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K; a.relu = d->relu; a.out_dtype = d->out_dtype;
+    if (cell) {
+        a.cell_c = cell->c; a.cell_h = cell->h; a.cell_t0 = cell->t0; a.cell_t1 = cell->t1;
+        a.cell_ld0 = cell->ld0; a.cell_ld1 = cell->ld1; a.cell_hd = cell->hd;
+    }
     hipStream_t s = (hipStream_t)stream;
     // every row block re-reads its 128 weight columns from L2: 32-row blocks halve that traffic and pay
     // off once there are still two workgroups per CU (the vocabulary projection)
@@ -548,6 +620,7 @@ extern "C" int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream) {
     if (mt == 2) return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 2>(a, s) : launch_skinny<float, 2>(a, s);
     return d->dtype == MIC_BF16 ? launch_skinny<bf16_t, 1>(a, s) : launch_skinny<float, 1>(a, s);
 }
+}  // namespace
 
 extern "C" int mic_linear_skinny(const void* x, int ld_x, const void* wf, const float* bias, void* out, int out_dtype, int ldc,
                                  int dtype, int M, int N, int K, int relu, void* stream) {

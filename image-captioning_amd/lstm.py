@@ -93,7 +93,8 @@ class ImageCaptioner:
         f32 = torch.float32
         t = {"xh": [torch.zeros(N, dec.kpad[l], dtype=d, device=dev) for l in range(dec.layers)],
              "h": [torch.zeros(N, dec.Hd, dtype=f32, device=dev) for _ in range(dec.layers)],
-             "c": [torch.zeros(N, dec.Hd, dtype=f32, device=dev) for _ in range(dec.layers)]}
+             "c": [torch.zeros(N, dec.Hd, dtype=f32, device=dev) for _ in range(dec.layers)],
+             "hstage": [torch.zeros(N, dec.kpad[l], dtype=d, device=dev) for l in range(dec.layers)]}
         if shared is None:
             shared = {"gates": torch.empty(N, 4 * dec.Hd, dtype=f32, device=dev), "hn": torch.empty(N, dec.Hd, dtype=f32, device=dev),
                       "hnt": torch.zeros(N, dec.out_k, dtype=d, device=dev), "logits": torch.empty(N, dec.vocab, dtype=f32, device=dev)}
@@ -102,6 +103,7 @@ class ImageCaptioner:
         ws.N = N
         for l in range(dec.layers):
             ws.xh[l], ws.h[l], ws.c[l] = t["xh"][l].data_ptr(), t["h"][l].data_ptr(), t["c"][l].data_ptr()
+            ws.hstage[l] = t["hstage"][l].data_ptr()
         ws.gates, ws.hn, ws.hnt, ws.logits = (t[k].data_ptr() for k in ("gates", "hn", "hnt", "logits"))
         return ws, t, shared
 

@@ -346,6 +346,13 @@ def build_lstm_decoder(sd: SD, kind: str, dtype: torch.dtype, device) -> tuple:
         # fragment-ordered copy (rows padded to 128, K to kp) for the weight-streaming GEMM of the decode steps
         dec.wf[l] = keep(frag_matrix(_pad_rows(torch.nn.functional.pad(torch.cat([wi, wh], dim=1).float(), (0, kp - wi.shape[1] - Hd))), dtype, device))
         dec.b[l] = keep(vector(sd[f"decoder.lstm.bias_ih_l{l}"] + sd[f"decoder.lstm.bias_hh_l{l}"], device))
+        # the same in unit-major row order (row 4u + g = gate g of unit u; nn.LSTM stacks the gates i, f, g, o): the gate GEMM
+        # whose epilogue is the cell (mic_lstm_gates_cell)
+        perm = (torch.arange(4 * Hd).view(Hd, 4) % 4) * Hd + torch.arange(Hd).view(Hd, 1)
+        perm = perm.reshape(-1)
+        wcat = torch.nn.functional.pad(torch.cat([wi, wh], dim=1).float(), (0, kp - wi.shape[1] - Hd))
+        dec.wf_cell[l] = keep(frag_matrix(_pad_rows(wcat[perm]), dtype, device))
+        dec.b_cell[l] = keep(vector((sd[f"decoder.lstm.bias_ih_l{l}"] + sd[f"decoder.lstm.bias_hh_l{l}"])[perm], device))
     if kind == "intermediate":
         dec.ln_g = keep(vector(sd["decoder.layer_norm.weight"], device))
         dec.ln_b = keep(vector(sd["decoder.layer_norm.bias"], device))

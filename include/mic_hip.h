@@ -288,6 +288,15 @@ typedef struct mic_skinny_desc {
 } mic_skinny_desc;
 int mic_linear_skinny_ex(const mic_skinny_desc* d, void* stream);
 
+/* The gate GEMM of an LSTM layer with the cell in its epilogue (models/intermediate.py:59-63, models/basic.py:45-55:
+ * nn.LSTM's i, f, g, o from [x | h] W^T + b, then c' = f c + i g, h' = o tanh(c')).  d as for mic_linear_skinny_ex with
+ * N = 4 Hd and the weight rows / bias in UNIT-MAJOR order (row 4u + g = gate g of hidden unit u, g = 0..3 for input,
+ * forget, cell, output), so that a lane's four accumulators are the four gates of one unit; no activation, residual or
+ * statistics; d->out is not written.  c [M][Hd] fp32 is updated in place, h' goes to h [M][Hd] fp32 and, in d->dtype, to
+ * ht0 [M][ld0] and ht1 [M][ld1] (either may be NULL).  Every workgroup of the launch reads the rows of d->x, so ht0 / ht1
+ * must not overlap them (checked): the recurrent half of [x | h] is refreshed by whoever moves the state to the next step. */
+int mic_lstm_gates_cell(const mic_skinny_desc* d, float* c, float* h, void* ht0, int ld0, void* ht1, int ld1, int Hd, void* stream);
+
 /* One new query per row against that row's cached keys/values, all heads
  * (the attention inside nn.MultiheadAttention, torch/nn/functional.py:6578-6606, for the last
  * text position only; the rest of the prefix is what the cache holds).
@@ -713,6 +722,10 @@ typedef struct mic_lstm_decoder {
      * of at most 2048 rows then take the weight-streaming GEMM (mic_linear_skinny) instead of the tiled one */
     const void* wf[MIC_MAX_LAYERS];
     const void* out_wf;
+    /* optional: wf and b of a layer with rows in unit-major order (row 4u + g): mic_lstm_beam_steps then runs the layer's
+     * cell in the epilogue of its gate GEMM (mic_lstm_gates_cell) where the workspace has the staging rows for h' */
+    const void* wf_cell[MIC_MAX_LAYERS];
+    const float* b_cell[MIC_MAX_LAYERS];
 } mic_lstm_decoder;
 
 typedef struct mic_lstm_workspace {
@@ -725,6 +738,9 @@ typedef struct mic_lstm_workspace {
     void* hnt;                  /* [N][out_k] dtype */
     float* logits;              /* [N][vocab] */
     float* scratch;             /* [N][max(E,Hd)] fp32 */
+    void* hstage[MIC_MAX_LAYERS]; /* optional [N][kpad] dtype, laid out like xh: the recurrent half receives h' of a layer whose
+                                   * cell ran in the gate GEMM's epilogue (that launch is still reading xh); the beam tail
+                                   * gathers the survivors' rows from here */
 } mic_lstm_workspace;
 
 /* One LSTM decoder step (all layers + LayerNorm (intermediate) + vocabulary projection) from the

@@ -391,3 +391,62 @@ def test_lstm_cell_with_layernorm_equals_the_two_launches(amd, N, Hd, dtype):
     cn = torch.sigmoid(f) * c0.cpu().double() + torch.sigmoid(i) * torch.tanh(gg)
     hn_ref = torch.nn.functional.layer_norm(torch.sigmoid(o) * torch.tanh(cn), (Hd,), ga.cpu().double(), be.cpu().double(), 1e-5)
     torch.testing.assert_close(out[0][3].double(), hn_ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,E,Hd", [(192, 512, 512), (37, 256, 128), (5, 64, 96)])
+def test_lstm_gate_gemm_with_the_cell_in_its_epilogue(amd, N, E, Hd, dtype):
+    """mic_lstm_gates_cell (unit-major weight rows, the cell in the GEMM's epilogue) against the gate GEMM in nn.LSTM's row order
+    followed by mic_lstm_cell: the same accumulators meet the same cell arithmetic, so c', h' and the rounded copies agree
+    to the last bit or two of fp32 (the two kernels are compiled apart), and both match the cell in float64."""
+    L, W = amd._lib, amd.weights
+    g = torch.Generator().manual_seed(N + Hd)
+    km = W.k_multiple(dtype)
+    K = (E + Hd + km - 1) // km * km
+    w = torch.randn(4 * Hd, E + Hd, generator=g) / (E + Hd) ** 0.5
+    b = 0.1 * torch.randn(4 * Hd, generator=g)
+    xh = torch.zeros(N, K, dtype=dtype)
+    xh[:, :E + Hd] = torch.randn(N, E + Hd, generator=g).to(dtype)
+    c0 = torch.randn(N, Hd, generator=g)
+    perm = ((torch.arange(4 * Hd).view(Hd, 4) % 4) * Hd + torch.arange(Hd).view(Hd, 1)).reshape(-1)
+    wpad = torch.nn.functional.pad(w, (0, K - E - Hd))
+    wf = W.frag_matrix(W._pad_rows(wpad), dtype, DEV)
+    wf_cell = W.frag_matrix(W._pad_rows(wpad[perm]), dtype, DEV)
+    d_b, d_bc, d_xh = b.to(DEV), b[perm].contiguous().to(DEV), xh.to(DEV)
+    ld0, ld1 = Hd + 8, Hd + 24
+    out = []
+    for fused in (True, False):
+        c, h = c0.clone().to(DEV), torch.zeros(N, Hd, device=DEV)
+        t0, t1 = torch.zeros(N, ld0, device=DEV, dtype=dtype), torch.zeros(N, ld1, device=DEV, dtype=dtype)
+        if fused:
+            d = L.SkinnyDesc()
+            d.x, d.ld_x, d.wf, d.bias = d_xh.data_ptr(), K, wf_cell.data_ptr(), d_bc.data_ptr()
+            d.dtype, d.out_dtype, d.M, d.N, d.K = L.dtype_code(dtype), L.F32, N, 4 * Hd, K
+            L.check(L.lib.mic_lstm_gates_cell(C.byref(d), c.data_ptr(), h.data_ptr(), t0.data_ptr(), ld0, t1.data_ptr(), ld1, Hd, L.stream_ptr()),
+                    "mic_lstm_gates_cell")
+        else:
+            gates = torch.empty(N, 4 * Hd, device=DEV)
+            L.check(L.lib.mic_linear_skinny(d_xh.data_ptr(), K, wf.data_ptr(), d_b.data_ptr(), gates.data_ptr(), L.F32, 4 * Hd, L.dtype_code(dtype),
+                                            N, 4 * Hd, K, 0, L.stream_ptr()), "mic_linear_skinny")
+            L.check(L.lib.mic_lstm_cell(gates.data_ptr(), c.data_ptr(), h.data_ptr(), t0.data_ptr(), ld0, t1.data_ptr(), ld1, L.dtype_code(dtype), N, Hd,
+                                        L.stream_ptr()), "mic_lstm_cell")
+        torch.cuda.synchronize()
+        out.append([v.float().cpu() for v in (c, h, t0, t1)])
+    tol = dict(rtol=2e-6, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    for i, (x, y) in enumerate(zip(*out)):
+        torch.testing.assert_close(x, y, **(tol if i >= 2 else dict(rtol=2e-6, atol=2e-6)))
+    assert torch.equal(out[0][2][:, Hd:], torch.zeros(N, ld0 - Hd)) and torch.equal(out[0][3][:, Hd:], torch.zeros(N, ld1 - Hd))
+    pre = xh.double() @ wpad.to(dtype).double().t() + b.double()
+    i_, f_, g_, o_ = pre.chunk(4, dim=1)
+    cn = torch.sigmoid(f_) * c0.double() + torch.sigmoid(i_) * torch.tanh(g_)
+    hn = torch.sigmoid(o_) * torch.tanh(cn)
+    t32 = dict(rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(out[0][0].double(), cn, **t32)
+    torch.testing.assert_close(out[0][1].double(), hn, **t32)
+    # h' must not land in the rows the launch is reading
+    d = L.SkinnyDesc()
+    d.x, d.ld_x, d.wf, d.bias = d_xh.data_ptr(), K, wf_cell.data_ptr(), d_bc.data_ptr()
+    d.dtype, d.out_dtype, d.M, d.N, d.K = L.dtype_code(dtype), L.F32, N, 4 * Hd, K
+    c, h = c0.clone().to(DEV), torch.zeros(N, Hd, device=DEV)
+    rc = L.lib.mic_lstm_gates_cell(C.byref(d), c.data_ptr(), h.data_ptr(), d_xh.data_ptr() + E * d_xh.element_size(), K, None, 0, Hd, L.stream_ptr())
+    assert rc != 0 and b"overwrite" in L.lib.mic_last_error()
