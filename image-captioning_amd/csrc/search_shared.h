@@ -207,7 +207,7 @@ struct TailArgs {
 template <int K, int G, int NWG> struct TailShared {
     SelShared sh;
     float red[G][NWG];
-    KV wbest[G][NWG];
+    KV wbest[G][NWG][K];
     float tv[K * K];
     int32_t ti[K * K];
 };
@@ -295,28 +295,36 @@ __device__ __forceinline__ void beam_tail_body(const TailArgs& a, int img, int t
                 }
             }
         }
+        // each wave extracts its own first K in order (no barrier: the exchange is inside the wave), then the first lanes of
+        // the group rank the NWG * K wave candidates: the row's first K are among them, and ranking them gives the order a
+        // round-by-round extraction over the whole group would
+#pragma unroll
         for (int r = 0; r < K; ++r) {
             const KV wb = wave_best(loc[0]);
-            if (lane == 0) wbest[grp][gw] = wb;
-            __syncthreads();
-            KV best = wbest[grp][0];
+            if (lane == 0) wbest[grp][gw][r] = wb;
+            if (loc[0].idx == wb.idx && wb.idx != 0x7fffffff) {  // this thread owned the wave's winner: pop
 #pragma unroll
-            for (int w = 1; w < NWG; ++w)
-                if (before(wbest[grp][w], best)) best = wbest[grp][w];
-            if (on) {
-                if (loc[0].idx == best.idx && best.idx != 0x7fffffff) {  // this thread owned the winner: emit and pop
-                    tv[row * K + r] = best.key;
-                    ti[row * K + r] = best.idx;
-#pragma unroll
-                    for (int k = 0; k < K - 1; ++k) loc[k] = loc[k + 1];
-                    loc[K - 1] = KV{-INFINITY, 0x7fffffff};
-                } else if (best.idx == 0x7fffffff && gt == 0) {  // fewer than K entries in the row
-                    tv[row * K + r] = -INFINITY;
-                    ti[row * K + r] = 0;
-                }
+                for (int k = 0; k < K - 1; ++k) loc[k] = loc[k + 1];
+                loc[K - 1] = KV{-INFINITY, 0x7fffffff};
             }
-            __syncthreads();
         }
+        __syncthreads();
+        if (on && gt < NWG * K) {
+            const KV mine = wbest[grp][gt / K][gt % K];
+            int rank = 0;
+#pragma unroll
+            for (int o = 0; o < NWG * K; ++o) {
+                const KV other = wbest[grp][o / K][o % K];
+                rank += before(other, mine) || (other.key == mine.key && other.idx == mine.idx && o < gt);  // the empty entries tie
+            }
+            if (rank < K) {
+                const bool empty = mine.idx == 0x7fffffff;  // fewer than K entries in the row
+                tv[row * K + rank] = empty ? -INFINITY : mine.key;
+                ti[row * K + rank] = empty ? 0 : mine.idx;
+            }
+        }
+        // (another pass writes wbest only behind the barriers of its own reductions; after the last pass the selection's
+        // first barrier publishes tv / ti)
     }
     if (tid < a.b.n_live_slots) slot_store(a.b, sh, tid, slot);
     beam_select_body(a.b, img, lane, tid < 64, sh, tv, ti, tid >> 6, G * NWG);
