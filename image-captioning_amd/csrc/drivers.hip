@@ -768,12 +768,12 @@ extern "C" int mic_tr_sample_steps(const mic_tr_decoder* dec, const mic_tr_works
 // ---------------------------------------------------------------------------------------------
 namespace {
 // skip_embed: the input half of xh[0] already holds the embedding of this step's tokens (written by the previous step's tail)
-// whether layer l's cell can run in the epilogue of its gate GEMM: unit-major weights, a staging row for h', the
-// weight-streaming GEMM's row limit, and not the top layer of the intermediate model when that one's cell carries the LayerNorm
+// whether layer l's cell can run in the epilogue of its gate GEMM: unit-major weights, a staging row for h' and the
+// weight-streaming GEMM's row limit.  The top layer of the intermediate model then takes the LayerNorm as a launch of its
+// own, which is shorter than the cell + LayerNorm launch it replaces (that one reads the whole gate matrix back).
 bool lstm_cell_fusable(const mic_lstm_decoder* dec, const mic_lstm_workspace* ws, int l) {
     static const bool off = getenv("MIC_NO_CELL_FUSE") != nullptr;  // comparison runs
-    if (off || !dec->wf_cell[l] || !dec->b_cell[l] || !ws->hstage[l] || ws->N > 2048) return false;
-    return !(l + 1 == dec->layers && dec->kind == 1 && mic_lstm_cell_ln_supported(dec->Hd));
+    return !off && dec->wf_cell[l] && dec->b_cell[l] && ws->hstage[l] && ws->N <= 2048;
 }
 
 // fuse_cell: the caller moves h' from ws->hstage[l] into the recurrent half of the next step's [x | h] rows (the beam tail's

@@ -723,7 +723,8 @@ typedef struct mic_lstm_decoder {
     const void* wf[MIC_MAX_LAYERS];
     const void* out_wf;
     /* optional: wf and b of a layer with rows in unit-major order (row 4u + g): mic_lstm_beam_steps then runs the layer's
-     * cell in the epilogue of its gate GEMM (mic_lstm_gates_cell) where the workspace has the staging rows for h' */
+     * cell in the epilogue of its gate GEMM (mic_lstm_gates_cell) where the workspace has the staging rows for h' (the
+     * intermediate model's LayerNorm then follows the top layer as mic_layernorm) */
     const void* wf_cell[MIC_MAX_LAYERS];
     const float* b_cell[MIC_MAX_LAYERS];
 } mic_lstm_decoder;
