@@ -9,6 +9,8 @@ from __future__ import annotations
 from collections import Counter
 from typing import Optional
 
+from .detok import treebank_detokenize
+
 PAD, SOS, EOS, UNK = "<PAD>", "<SOS>", "<EOS>", "<UNK>"  # constants.py:39-42
 
 
@@ -60,11 +62,10 @@ class Vocabulary:
         return self.sp.id_to_piece(idx)
 
     def encode_as_words(self, idxs) -> str:
-        """ids -> text.  Word mode drops ids 0,1,2 and joins with spaces; the reference then runs
-        NLTK's Treebank detokeniser (punctuation re-attachment), which is not installed here, so
-        strings can differ from the reference's in spacing around punctuation only."""
+        """ids -> text (dataset/vocabulary.py:106-121).  Word mode drops ids 0, 1, 2 and detokenises the words the way NLTK's
+        TreebankWordDetokenizer does (detok.py restates its rules: NLTK is not installed here)."""
         if self.tokenizer == "word":
-            return " ".join(self.idx_to_str(int(i)) for i in idxs if int(i) not in (0, 1, 2))
+            return treebank_detokenize(self.idx_to_str(int(i)) for i in idxs if int(i) not in (0, 1, 2))
         return self.sp.decode_ids([int(i) for i in idxs])
 
     def load_dict(self, state_dict: dict) -> None:

@@ -24,6 +24,29 @@ def test_vocabulary_mirror():
     assert counts[0] == 0 and counts[1] == 50 and counts[4] == 5
 
 
+def test_word_captions_are_detokenised_the_treebank_way():
+    """dataset/vocabulary.py:113-117 detokenises with NLTK's TreebankWordDetokenizer.  NLTK is not installed, so the known
+    answers are the examples of that class's own documentation (tokens as NLTK's word tokenizer produces them), plus what
+    those rules do to caption-like token lists."""
+    from image_captioning_amd.detok import treebank_detokenize as d
+    assert d(["Good", "muffins", "cost", "$", "3.88", "in", "New", "York.", "Please", "buy", "me", "two", "of", "them.", "Thanks", "."]) == \
+        "Good muffins cost $3.88 in New York. Please buy me two of them. Thanks."
+    assert d(["hello", ",", "i", "ca", "n't", "feel", "my", "feet", "!", "Help", "!", "!"]) == "hello, i can't feel my feet! Help!!"
+    assert d(["hello", ",", "i", "ca", "n't", "feel", ";", "my", "feet", "!", "Help", "!", "!", "He", "said", ":", "Help", ",", "help", "?", "!"]) == \
+        "hello, i can't feel; my feet! Help!! He said: Help, help?!"
+    assert d(["a", "man", "'s", "dog", "is", "riding", "a", "surfboard", "."]) == "a man's dog is riding a surfboard."
+    assert d(["a", "man", ".", "a", "dog", "."]) == "a man . a dog."          # only the text's last period is re-attached
+    assert d(["``", "hello", "''", ",", "she", "said", "(", "quietly", ")", "."]) == '"hello", she said (quietly).'
+    assert d(["i", "can", "not", "wan", "na", "go", "--", "really"]) == "i cannot wanna go--really"
+    assert d([]) == "" and d(["dog"]) == "dog"
+    v = amd.Vocabulary("word")
+    words = ["a", "dog", ",", "running", "."]
+    for i, w in enumerate(words):
+        v.stoi_dict[w] = 4 + i
+        v.itos_dict[4 + i] = w
+    assert v.encode_as_words([1, 4, 5, 6, 7, 8, 2, 0]) == "a dog, running."
+
+
 def test_output_bias_matches_oracle():
     from oracle import captioner_oracle as O
     v = amd.Vocabulary.synthetic(200)
