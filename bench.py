@@ -228,8 +228,9 @@ def main():
                     "and workspaces each); with 1, the throughput of 3 lanes is measured after the timed region and reported beside it")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
     ap.add_argument("--decode-groups", type=int, default=1, help="concurrent beam-search sub-batches per GPU")
-    ap.add_argument("--concurrent-steps", type=int, default=12, help="steps of the 3-lane throughput measurement that follows the timed "
-                    "region at --lanes 1 (0 skips it, e.g. under a profiler, so that the kernel statistics are those of the timed region's schedule)")
+    ap.add_argument("--concurrent-steps", type=int, default=240, help="steps of the 3-lane throughput measurement that follows the timed "
+                    "region at --lanes 1: about two seconds of GPU work, long enough for an outside utilisation sampler to see the GPU "
+                    "busy (0 skips it, e.g. under a profiler, so that the kernel statistics are those of the timed region's schedule)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="transformer")
     ap.add_argument("--cpu-images", type=int, default=128, help="sample size of the CPU baseline (0 disables it)")
     ap.add_argument("--job-images", type=int, default=100_000, help="--workload job: images of the whole job, all ranks together")
