@@ -997,7 +997,7 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, float* __restr
     const int n = i / Hd, j = i - n * Hd;
     const float* g = gates + (long long)n * 4 * Hd;
     const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[Hd + j]), gg = tanhf(g[2 * Hd + j]), og = sigmoidf_(g[3 * Hd + j]);
-    const float cn = fg * c[i] + ig * gg;
+    const float cn = __builtin_fmaf(fg, c[i], ig * gg);  // spelt out: the same rounding wherever this cell is written (gemm_ln.hip has it too)
     const float hn = og * tanhf(cn);
     c[i] = cn;
     h[i] = hn;
@@ -1025,10 +1025,10 @@ __global__ void lstm_cell_ln_kernel(const float* __restrict__ gates, float* __re
             const float4 gi = *reinterpret_cast<const float4*>(g + j), gf = *reinterpret_cast<const float4*>(g + Hd + j);
             const float4 gc = *reinterpret_cast<const float4*>(g + 2 * Hd + j), go = *reinterpret_cast<const float4*>(g + 3 * Hd + j);
             float4 cv = *reinterpret_cast<const float4*>(c + (long long)row * Hd + j);
-            cv.x = sigmoidf_(gf.x) * cv.x + sigmoidf_(gi.x) * tanhf(gc.x);
-            cv.y = sigmoidf_(gf.y) * cv.y + sigmoidf_(gi.y) * tanhf(gc.y);
-            cv.z = sigmoidf_(gf.z) * cv.z + sigmoidf_(gi.z) * tanhf(gc.z);
-            cv.w = sigmoidf_(gf.w) * cv.w + sigmoidf_(gi.w) * tanhf(gc.w);
+            cv.x = __builtin_fmaf(sigmoidf_(gf.x), cv.x, sigmoidf_(gi.x) * tanhf(gc.x));
+            cv.y = __builtin_fmaf(sigmoidf_(gf.y), cv.y, sigmoidf_(gi.y) * tanhf(gc.y));
+            cv.z = __builtin_fmaf(sigmoidf_(gf.z), cv.z, sigmoidf_(gi.z) * tanhf(gc.z));
+            cv.w = __builtin_fmaf(sigmoidf_(gf.w), cv.w, sigmoidf_(gi.w) * tanhf(gc.w));
             hv[k] = make_float4(sigmoidf_(go.x) * tanhf(cv.x), sigmoidf_(go.y) * tanhf(cv.y), sigmoidf_(go.z) * tanhf(cv.z),
                                 sigmoidf_(go.w) * tanhf(cv.w));
             *reinterpret_cast<float4*>(c + (long long)row * Hd + j) = cv;

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64 * NWV, (MT == 2 && NWV == 4) ? 3 : (MT == 1 && N
                 const int m = m0 + i * 16 + r;
                 if (m >= a.M) continue;
                 const float ig = skinny_sigmoid(v[i][j][0]), fg = skinny_sigmoid(v[i][j][1]), gg = tanhf(v[i][j][2]), og = skinny_sigmoid(v[i][j][3]);
-                const float cn = fg * cprev[i][j] + ig * gg;
+                const float cn = __builtin_fmaf(fg, cprev[i][j], ig * gg);
                 const float hn = og * tanhf(cn);
                 const long long ci = (long long)m * a.cell_hd + u;
                 a.cell_c[ci] = cn;
