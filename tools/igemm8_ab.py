@@ -21,7 +21,7 @@ SHAPES = {  # name: B, H, Cin, Cout, k, stride, residual
     "s1c1": (256, 28, 512, 128, 1, 1, False), "s0c1": (256, 56, 256, 64, 1, 1, False), "s1ds": (256, 56, 256, 512, 1, 2, False),
     "s1c3": (256, 28, 128, 512, 1, 1, True), "s0c2": (256, 56, 64, 64, 3, 1, False), "s0c3": (256, 56, 64, 256, 1, 1, True),
     "s1b0c2": (256, 56, 128, 128, 3, 2, False), "s2b0c2": (256, 28, 256, 256, 3, 2, False), "s3b0c2": (256, 14, 512, 512, 3, 2, False),
-    "ckv": (256, 7, 512, 1024, 1, 1, False),
+    "ckv": (256, 7, 512, 1024, 1, 1, False), "ckv6": (256, 7, 512, 6144, 1, 1, False),
     # Swin-V2 GEMMs without the LayerNorm epilogue at batch 512: QKV and MLP-1 of the four stages
     "w0qkv": (512, 56, 96, 288, 1, 1, False), "w0fc1": (512, 56, 96, 384, 1, 1, False),
     "w1qkv": (512, 28, 192, 576, 1, 1, False), "w1fc1": (512, 28, 192, 768, 1, 1, False),
