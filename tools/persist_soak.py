@@ -3,7 +3,7 @@
 3 layers, V = 3500, 30 steps), fresh features every search, each compared id for id, length for length and score bit for
 bit with the launch-per-sublayer schedule, and the device error word checked after every search.  A lost hand-off between
 workgroups shows up as a differing search or a non-zero error word, never as a hang (every wait in the kernel is bounded).
-usage: persist_soak.py [searches]"""
+usage: persist_soak.py [searches [steps]]   (more than 31 steps take the six-positions-per-wave build of the attention phase)"""
 import os
 import sys
 import time
@@ -32,7 +32,8 @@ class IdVocab:
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    V, H, Ly, PT, S, B, T = 3500, 512, 3, 31, 49, 256, 30
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    V, H, Ly, PT, S, B = 3500, 512, 3, T + 1, 49, 256
     sd = amd.weights.random_transformer_state(V, H, Ly, PT, seed=3)
     models = {p: amd.transformer.ImageCaptioner(IdVocab(V), 2, torch.bfloat16, encoder="none", persistent=p).load_state_dict(sd).to(DEV)
               for p in (False, True)}
