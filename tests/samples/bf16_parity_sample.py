@@ -4,7 +4,7 @@ larger sample than the test suite affords, the three measures of tests/test_gpu_
 features; the reported score of each caption against the oracle's fp32 teacher-forced score of the same tokens; that score
 against the oracle's own best beam.  (With random-init weights the step distributions are nearly flat, so which of several
 near-tied tokens wins is not a measure; the arithmetic along a sequence is.)
-usage: bf16_parity_sample.py [images]"""
+usage: python tests/samples/bf16_parity_sample.py [images]"""
 import os
 import sys
 import time
@@ -12,10 +12,11 @@ import time
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import image_captioning_amd as amd  # noqa: E402
 import bench  # noqa: E402
-from oracle import captioner_oracle as O  # noqa: E402  (the checker, as in tests/)
+from oracle import captioner_oracle as O  # noqa: E402  (the checker)
 
 
 def main():

@@ -2,17 +2,18 @@
 """fp32 LSTM searches (intermediate and basic decoders: E = H = 512, 2 layers, V = 3500, max_len = 30) against the fp32 CPU
 oracle on a larger sample than the test suite affords: greedy and beam-3 captions must be identical caption by caption
 (models/image_captioner.py:55-159 downstream of the encoder).
-usage: fp32_parity_lstm.py [images]"""
+usage: python tests/samples/fp32_parity_lstm.py [images]"""
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import image_captioning_amd as amd  # noqa: E402
-from oracle import captioner_oracle as O  # noqa: E402  (the checker, as in tests/)
+from oracle import captioner_oracle as O  # noqa: E402  (the checker)
 from persist_soak import IdVocab  # noqa: E402
 
 

@@ -4,7 +4,7 @@ oracle on a larger sample than the test suite affords: token ids must be identic
 log-probabilities within 1e-3 (the reference's algorithm: models/transformer.py:458-640).  Prints one line per search mode.
 With a hidden size of 256 (rows of 1 KiB in fp32) and at most 256 images the search takes the one-launch step, the schedule
 the bf16 benchmark times; at 512 the launch-per-sub-layer schedules.
-usage: fp32_parity_sample.py [images [hidden size]]"""
+usage: python tests/samples/fp32_parity_sample.py [images [hidden size]]"""
 import os
 import sys
 import time
@@ -12,10 +12,11 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import image_captioning_amd as amd  # noqa: E402
-from oracle import captioner_oracle as O  # noqa: E402  (the checker, as in tests/)
+from oracle import captioner_oracle as O  # noqa: E402  (the checker)
 from persist_soak import IdVocab  # noqa: E402
 
 
